@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s at 1920x1080x128 (BASELINE.json config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* renders the config-2 frame twice -- once with the normal shader (mode 4) and once
+with the Lambertian shader (mode 0), the two shaders config 2 names -- through
+RenderLoop.forward, i.e. the fused HIP kernel k_render_fwd (camera -> 128 march iterations
+-> distance -> tetrahedral normals -> shader).  Camera buffers, scene parameters and output
+images are resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling by pixel-row tiles.
+The frame is 1920 x (1080*N); rank r renders rows [1080 r, 1080 (r+1)) and the tiles are
+gathered to rank 0 over RCCL on a side stream, overlapped with the next frame's render.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PX = 3.45e-6
+W, H_TILE, STEPS_MARCH, EPS = 1920, 1080, 128, 5e-2
+MODES = (4, 0)                 # normal, lambertian
+BYTES_PER_RAY = 36             # 12 B origin + 12 B direction + 12 B RGB
+FLOPS_PER_EVAL = 80            # scene2, incl. 5 sqrt
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL tile gather")
+    ap.add_argument("--no-early-out", action="store_true")
+    ap.add_argument("--tile8x8", action="store_true")
+    ap.add_argument("--camera-z", type=float, default=-3.0, help="camera position (0,0,z); SURVEY 8d uses -3 and +1")
+    ap.add_argument("--skip-backward", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """The oracle (eager PyTorch CPU restatement of the reference, bit-exact with it in the
+    build container) on this box's host cores, on a bounded sample of the same workload:
+    every 2nd pixel row and column of the 1920x1080 grid (960x540 rays, same ray
+    distribution), 128 steps, normal + Lambertian frames; best of 2 after one warm-up."""
+    from oracle import sdf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bufs = O.camera_buffers(1, W, H_TILE, PX * H_TILE, PX * W, PX * H_TILE)
+    sub = tuple(b[:, ::2, ::2].contiguous() for b in bufs)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]])
+    t = torch.tensor([[0.0, 0.0, -3.0]])
+    spec = O.scene_test2()
+    rays = sub[0].shape[1] * sub[0].shape[2] * len(MODES)
+    best = float("inf")
+    with torch.no_grad():
+        for it in range(3):
+            t0 = time.perf_counter()
+            for m in MODES:
+                O.render(spec, sub, q, t, m, 1, STEPS_MARCH, EPS)
+            dt = time.perf_counter() - t0
+            if it > 0:
+                best = min(best, dt)
+    return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "960x540 rays (every 2nd row/col of the 1920x1080 grid) x128 steps, normal+lambertian, "
+                      "oracle/sdf_oracle.py eager fp32, best of 2",
+            "seconds": best}
+
+
+def backward_probe(dev):
+    """Secondary metric 'fwd+bwd ms/frame' (BASELINE config 4 shape): closed make_test_scene,
+    512x512, 64 steps, Lambertian MSE loss, gradients of all 40 scene parameters."""
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.scene.scene_registry import make_closed_test_scene
+    h = w = 512
+    scene = make_closed_test_scene()
+    loop = RenderLoop(scene, num_cameras=1, px_width=w, px_height=h, focal_length=PX * h, sensor_width=PX * w,
+                      sensor_height=PX * h, normals_eps=EPS).to(dev)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
+    t = torch.tensor([[0.0, 0.0, -1.0]], device=dev)
+    target = torch.rand(1, h, w, 1, device=dev)
+    fwd = bwd = 0.0
+    reps = 5
+    for it in range(reps + 1):
+        for p in scene.parameters():
+            p.grad = None
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        loss = (loop(q, t, 0, 1, 64)[..., :1] - target).pow(2).mean()
+        e1.record()
+        loss.backward()
+        e2.record()
+        torch.cuda.synchronize()
+        if it > 0:
+            fwd += e0.elapsed_time(e1)
+            bwd += e1.elapsed_time(e2)
+    return {"config": "closed make_test_scene 512x512x64, lambertian MSE, 40 parameters",
+            "fwd_ms": fwd / reps, "bwd_ms": bwd / reps, "fwd_bwd_ms": (fwd + bwd) / reps}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build_library()
+    if dist is not None:
+        dist.barrier()
+
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+
+    h_total = H_TILE * world
+    loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=h_total, focal_length=PX * H_TILE,
+                      sensor_width=PX * W, sensor_height=PX * h_total, normals_eps=EPS,
+                      early_out=not args.no_early_out, tile8x8=args.tile8x8).to(dev)
+    rows = (rank * H_TILE, (rank + 1) * H_TILE)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
+    t = torch.tensor([[0.0, 0.0, args.camera_z]], device=dev)
+    rays_per_frame = W * H_TILE
+
+    gather = dist is not None and not args.no_gather
+    comm = torch.cuda.Stream(device=dev) if gather else None
+    gathered = None
+    if gather and rank == 0:
+        gathered = [[torch.empty(1, H_TILE, W, 3, device=dev) for _ in range(world)] for _ in range(2)]
+
+    kernel_ms = []
+
+    def one_step(step_idx, timed):
+        handles = []
+        for j, mode in enumerate(MODES):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            img = loop(q, t, mode, 1, STEPS_MARCH, rows=rows)
+            if timed:
+                e1.record()
+                kernel_ms.append((e0, e1))
+            if gather:
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    img.record_stream(comm)
+                    dist.gather(img, gathered[j] if rank == 0 else None, dst=0)
+            handles.append(img)
+        return handles
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            one_step(i, False)
+        if comm is not None:
+            torch.cuda.current_stream().wait_stream(comm)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i, True)
+        if comm is not None:
+            torch.cuda.current_stream().wait_stream(comm)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    per_launch_ms = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(len(kernel_ms), 1)
+    total_rays = rays_per_frame * len(MODES) * args.steps * world
+    value = total_rays / elapsed / 1e6
+
+    if rank == 0:
+        evals = rays_per_frame * (STEPS_MARCH + 6)
+        ach_gbs = rays_per_frame * BYTES_PER_RAY / (per_launch_ms * 1e-3) / 1e9
+        ach_tf = evals * FLOPS_PER_EVAL / (per_launch_ms * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(prof):
+            with open(prof) as f:
+                traffic = json.load(f).get("k_render_fwd_hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/sec at 1920x1080x128 iters; fwd+bwd ms/frame",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: make_test_scene2 (room shell + sphere/torus/capsule), "
+                                   "1920x1080 pinhole ray grid per GPU, 128 march iters, normal + Lambertian "
+                                   "frames per step, fp32", "frames_per_step": len(MODES),
+                       "rays_per_frame": rays_per_frame, "camera": [0.0, 0.0, args.camera_z],
+                       "early_out": not args.no_early_out, "wave_tile": "8x8" if args.tile8x8 else "64x1",
+                       "parallelism": f"row-tiles x{world}" + (" + RCCL gather" if gather else "")},
+            "ray_sdf_evals_per_s": value * 1e6 * (STEPS_MARCH + 6),
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_render_fwd", "kernel_ms": per_launch_ms,
+                         "algorithmic_bytes_per_launch": rays_per_frame * BYTES_PER_RAY,
+                         "binding": "fp32-valu (SURVEY D8: 298 flop/B, the fused frame cannot be HBM bound)",
+                         "valu": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach_tf / VALU_PEAK_TFLOPS,
+                                  "algorithmic_flops_per_launch": evals * FLOPS_PER_EVAL,
+                                  "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer"}},
+        }
+        if not args.skip_backward:
+            out["fwd_bwd"] = backward_probe(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

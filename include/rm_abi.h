@@ -1,0 +1,195 @@
+/*
+ * rm_abi.h -- C ABI of the MI355X (gfx950) sphere-tracing library, librm_hip.so.
+ *
+ * The reference (kyle-rosa/ray_marching) has no FFI boundary: its operator API
+ * is Python nn.Module.__call__ on torch tensors.  These entry points are what a
+ * binding for its hot path binds instead of the ATen op stream; each one cites
+ * the reference interface it replaces.  Plain pointers and sizes only, no torch
+ * types.  The Python host (ray_marching_amd/_abi.py) calls them through ctypes
+ * with tensor.data_ptr() and the current HIP stream handle.
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller; the
+ *     library never allocates, frees or synchronises;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); calls are re-entrant per stream;
+ *   - return value 0 = enqueued, negative = error (RM_E_*), message available
+ *     from rm_last_error() on the calling thread; no C++ exception crosses;
+ *   - all arithmetic is IEEE fp32 (RM_DTYPE_F32).  Arrays are contiguous,
+ *     channels-last: points [n,3], images [N,rows,W,3].
+ */
+#ifndef RM_ABI_H
+#define RM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 3
+
+enum {
+  RM_OK = 0,
+  RM_E_BADARG = -1,      /* null pointer / negative size / bad mode */
+  RM_E_PROGRAM = -2,     /* scene program failed validation */
+  RM_E_TOO_LARGE = -3,   /* scene does not fit the LDS budget */
+  RM_E_LAUNCH = -4       /* HIP launch error */
+};
+
+/* ---- scene program ------------------------------------------------------
+ * A scene (the reference's nn.Module tree: scene/primitives.py:6-102,
+ * scene/transformations.py:8-132) is compiled by the host into a flat list of
+ * 4-word instructions {opcode, param_offset, aux0, aux1} evaluated left to
+ * right, plus one packed fp32 parameter block in named_parameters() order.
+ */
+enum {
+  RM_OP_END = 0,
+  RM_OP_SPHERE = 1,        /* P: radius                     primitives.py:11-17  */
+  RM_OP_BOX = 2,           /* P: halfsides[3]               primitives.py:25-33  */
+  RM_OP_PLANE = 3,         /*                               primitives.py:40-41  */
+  RM_OP_LINE = 4,          /* P: start[3] end[3] radius; aux0 = derived offset (AB[3], AB/|AB|^2[3])  primitives.py:51-61 */
+  RM_OP_DISK = 5,          /* P: radius                     primitives.py:69-82  */
+  RM_OP_TORUS = 6,         /* P: radius1 radius2            primitives.py:91-102 */
+  RM_OP_AFFINE_PUSH = 7,   /* P: translation[3] orientation[4]   transformations.py:33-42 */
+  RM_OP_AFFINE_POP = 8,    /* P: same offset as the matching PUSH */
+  RM_OP_UNION_BEGIN = 9,   /*                               transformations.py:90-94 */
+  RM_OP_FOLD_MIN = 10,     /* aux0 = tape slot */
+  RM_OP_UNION_END = 11,    /* aux0 = first tape slot, aux1 = child count */
+  RM_OP_SMOOTH_BEGIN = 12, /*                               transformations.py:67-71 */
+  RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot */
+  RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count */
+  RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
+  RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
+  RM_OP__COUNT = 17
+};
+
+typedef struct RmScene {
+  const int32_t* program;  /* device, n_instr * 4 int32 */
+  const float* params;     /* device, n_params fp32 (raw parameters) */
+  int32_t n_instr;
+  int32_t n_params;        /* raw parameter floats = length of every grad_params vector */
+  int32_t n_derived;       /* derived constants appended in LDS after the raw block */
+  int32_t stack_floats;    /* per-ray evaluation stack depth (floats) */
+  int32_t n_slots;         /* per-ray tape slots (fold / onion inputs) */
+} RmScene;
+
+/* PinholeCamera buffers (rendering/ray_marching.py:26-50). */
+typedef struct RmCamera {
+  const float* ray_positions;   /* device [N,H,W,3] camera-frame origins */
+  const float* ray_directions;  /* device [N,H,W,3] camera-frame unit directions */
+  int32_t num_cameras, height, width;
+} RmCamera;
+
+/* SDFNormals constants (rendering/ray_marching.py:96-113), host memory. */
+typedef struct RmTetra {
+  float offsets[12];   /* 4 taps x 3, already scaled by normals_eps */
+  float inverse[9];    /* inverse of the relative offsets, row major */
+  float lap_scale;     /* 6 / eps^2 */
+} RmTetra;
+
+/* shader modes, order of rendering/shader.py:204-209 */
+enum {
+  RM_MODE_LAMBERTIAN = 0, RM_MODE_DISTANCE = 1, RM_MODE_PROXIMITY = 2, RM_MODE_VIGNETTE = 3,
+  RM_MODE_NORMAL = 4, RM_MODE_LAPLACIAN = 5, RM_MODE_TANGENT = 6, RM_MODE_SPIN = 7
+};
+
+/* flags */
+enum {
+  RM_FLAG_EARLY_OUT = 1,   /* wave-uniform exit once every ray of the wave sits on a bit-exact
+                              fixed point / 2-cycle of the march map (results unchanged) */
+  RM_FLAG_TILE8X8 = 2      /* a wave covers an 8x8 pixel tile instead of 64 pixels of one row */
+};
+
+int rm_abi_version(void);
+const char* rm_last_error(void);
+
+/* Workspace sizing for the backward entry points: number of floats of
+ * `partials` needed for a launch over n rays. */
+int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n);
+
+/* scene(query[...,3]) -> [...,1]          (every forward() in scene/primitives.py, transformations.py) */
+int rm_sdf_forward(const RmScene* scene, const float* points /*device [n,3]*/,
+                   float* dist /*device [n]*/, int64_t n, void* stream);
+
+/* VJP of rm_sdf_forward: grad_points[n,3] (nullable) and grad_params[n_params]
+ * (nullable, OVERWRITTEN with the deterministic sum over rays). */
+int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad_dist /*[n]*/,
+                    float* grad_points, float* grad_params, float* partials, int64_t n, void* stream);
+
+/* SDFMarcher.forward (rendering/ray_marching.py:72-84): p <- f(p)*v + p, `steps` times.
+ * traj (nullable): device [steps,n,3], iterate p_i BEFORE step i (needed by backward).
+ * nexec (nullable): device int32 [n], steps executed before the early-out fixed point. */
+int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, float* out_pos,
+                     float* traj, int32_t* nexec, int64_t n, int32_t steps, int32_t flags, void* stream);
+
+/* VJP of rm_march_forward w.r.t. pos, dirs (nullable) and parameters. */
+int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj, const int32_t* nexec,
+                      const float* grad_out /*[n,3]*/, float* grad_pos, float* grad_dirs,
+                      float* grad_params, float* partials, int64_t n, int32_t steps, void* stream);
+
+/* SDFNormals.forward (rendering/ray_marching.py:115-125). */
+int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* coords /*[n,3]*/,
+                       float* normals /*[n,3]*/, float* laplacian /*[n]*/, int64_t n, void* stream);
+
+int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float* coords,
+                        const float* grad_normals /*[n,3] nullable*/, const float* grad_lap /*[n] nullable*/,
+                        float* grad_coords, float* grad_params, float* partials, int64_t n, void* stream);
+
+/* PinholeCamera.forward (rendering/ray_marching.py:57-64). frames: [N,3,3]. */
+int rm_camera_forward(const RmCamera* cam, const float* orientation /*device [N,4]*/,
+                      const float* translation /*device [N,3]*/, float* out_pos, float* out_dirs,
+                      float* out_frames, void* stream);
+
+/* RenderLoop.forward (control.py:231-258), fused: camera -> march -> distance ->
+ * normals/laplacian -> shader, rows [row_begin,row_end) of every camera.
+ *   image   : device [N,rows,W,3] fp32.
+ *   p_final : nullable [N,rows,W,3]; traj: nullable [steps,N*rows*W,3]; nexec nullable.
+ *   minmax  : device uint32[4], required for modes 1,2,5 (global min/max, shader.py:35-36,
+ *             52-53, 84).  The kernel leaves the un-normalised value in `image` and folds
+ *             its min/max into minmax; rm_shade_finish() then normalises.  Between the two
+ *             calls a multi-GPU host all-reduces minmax (rm_minmax_* helpers).
+ *   cmap    : device fp32 [cmap_size,3], required for modes 6,7.
+ */
+int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
+                      const float* orientation, const float* translation,
+                      float* image, float* p_final, float* traj, int32_t* nexec,
+                      uint32_t* minmax, const float* cmap, int32_t cmap_size,
+                      int32_t mode, int32_t degree, int32_t steps,
+                      int32_t row_begin, int32_t row_end, int32_t flags, void* stream);
+
+/* minmax helpers: init to (+inf, -inf, no-NaN); decode to two floats {lo, hi};
+ * encode two floats back (after a host-side all-reduce). */
+int rm_minmax_init(uint32_t* minmax /*device*/, void* stream);
+int rm_minmax_decode(const uint32_t* minmax, float* lohi /*device [2]*/, void* stream);
+int rm_minmax_encode(const float* lohi /*device [2]*/, uint32_t* minmax, void* stream);
+
+/* second pass of the globally normalised shaders (modes 1, 2, 5), in place on image[n_pixels,3]. */
+int rm_shade_finish(float* image, int64_t n_pixels, const uint32_t* minmax, int32_t mode, void* stream);
+
+/* Shader.forward on tensors (rendering/shader.py:190-263): first pass for every mode.
+ * Inputs a mode does not read may be NULL.  frames: [N,3,3]; per-pixel arrays hold
+ * n_pixels = N * pixels_per_camera entries.  Modes 1,2,5 need minmax + rm_shade_finish. */
+int rm_shade_forward(const float* px_coords, const float* orientation, const float* frames, const float* dirs,
+                     const float* coords, const float* normals, const float* lap, const float* dist, float* image,
+                     uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
+                     int64_t n_pixels, int64_t pixels_per_camera, void* stream);
+
+/* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
+ * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten. */
+int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
+                       const float* orientation, const float* translation,
+                       const float* traj, const int32_t* nexec, const float* p_final,
+                       const float* grad_image, float* grad_params, float* partials,
+                       int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, void* stream);
+
+/* Host-side check of a compiled program BEFORE it is uploaded (host pointer):
+ * opcode range, parameter/slot/derived offsets inside their blocks, balanced
+ * begin/end and push/pop, stack depth <= stack_floats, exactly one result. */
+int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_params, int32_t n_derived,
+                        int32_t stack_floats, int32_t n_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RM_ABI_H */

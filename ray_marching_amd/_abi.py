@@ -1,0 +1,106 @@
+"""ctypes binding of librm_hip.so (C ABI declared in include/rm_abi.h).
+
+The library is the product; there is no Python/PyTorch fallback.  If the shared
+object is missing or does not export the ABI this module raises at import time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 3
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
+
+# opcodes (include/rm_abi.h)
+OP_SPHERE, OP_BOX, OP_PLANE, OP_LINE, OP_DISK, OP_TORUS = 1, 2, 3, 4, 5, 6
+OP_AFFINE_PUSH, OP_AFFINE_POP = 7, 8
+OP_UNION_BEGIN, OP_FOLD_MIN, OP_UNION_END = 9, 10, 11
+OP_SMOOTH_BEGIN, OP_FOLD_LSE, OP_SMOOTH_END = 12, 13, 14
+OP_ROUND, OP_ONION = 15, 16
+
+FLAG_EARLY_OUT, FLAG_TILE8X8 = 1, 2
+MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
+
+
+class RmScene(C.Structure):
+    _fields_ = [("program", C.c_void_p), ("params", C.c_void_p), ("n_instr", C.c_int32),
+                ("n_params", C.c_int32), ("n_derived", C.c_int32), ("stack_floats", C.c_int32),
+                ("n_slots", C.c_int32)]
+
+
+class RmCamera(C.Structure):
+    _fields_ = [("ray_positions", C.c_void_p), ("ray_directions", C.c_void_p),
+                ("num_cameras", C.c_int32), ("height", C.c_int32), ("width", C.c_int32)]
+
+
+class RmTetra(C.Structure):
+    _fields_ = [("offsets", C.c_float * 12), ("inverse", C.c_float * 9), ("lap_scale", C.c_float)]
+
+
+class RmError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "rm_abi_version": (C.c_int, []),
+    "rm_last_error": (C.c_char_p, []),
+    "rm_grad_partials_floats": (C.c_int64, [C.POINTER(RmScene), C.c_int64]),
+    "rm_validate_program": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rm_sdf_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, C.c_int64, _P]),
+    "rm_sdf_backward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "rm_march_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "rm_march_backward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "rm_normals_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, C.c_int64, _P]),
+    "rm_normals_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "rm_camera_forward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P]),
+    "rm_render_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
+                                    _P, _P, _P, _P, _P, _P, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "rm_minmax_init": (C.c_int, [_P, _P]),
+    "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
+    "rm_minmax_encode": (C.c_int, [_P, _P, _P]),
+    "rm_shade_finish": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P]),
+    "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int64, C.c_int64, _P]),
+    "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
+                                     _P, _P, _P, _P, _P, _P,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  ray_marching_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.rm_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"librm_hip.so ABI version {got}, expected {ABI_VERSION}: rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RmError(f"{what} failed ({code}): {lib.rm_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

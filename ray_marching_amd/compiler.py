@@ -1,0 +1,203 @@
+"""Scene compiler: nn.Module SDF tree -> flat program + packed parameter block.
+
+The reference evaluates a scene by recursing through ``nn.Module.forward``
+calls (scene/primitives.py, scene/transformations.py), one ATen op at a time.
+Here the tree is walked once on the host and lowered to the instruction list of
+``include/rm_abi.h`` (opcode, parameter offset, aux0, aux1), which the HIP
+kernels evaluate per ray.
+
+Parameter block layout = ``module.named_parameters()`` order (the reference's
+state_dict order), so gradient vectors map 1:1 back onto the ``nn.Parameter``s.
+Derived constants (capsule AB, AB/|AB|^2) get slots after the raw block; the
+kernels fill them in LDS.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi
+
+# backward-pass stack cost of each frame kind, in floats (forward uses fewer)
+_STACK_UNION, _STACK_SMOOTH, _STACK_AFFINE = 2, 2, 6
+
+
+@dataclass
+class CompiledScene:
+    program: np.ndarray                 # int32 [n_instr, 4]
+    leaves: list                        # nn.Parameter objects in block order
+    leaf_names: list
+    leaf_offsets: list
+    n_params: int
+    n_derived: int
+    stack_floats: int
+    n_slots: int
+    signature: tuple                    # topology key (ops + offsets), parameters excluded
+    _device_programs: dict = field(default_factory=dict)
+    _packed: dict = field(default_factory=dict)
+
+    @property
+    def n_instr(self):
+        return int(self.program.shape[0])
+
+    def device_program(self, device):
+        key = str(device)
+        t = self._device_programs.get(key)
+        if t is None:
+            t = torch.from_numpy(self.program.reshape(-1).copy()).to(device)
+            self._device_programs[key] = t
+        return t
+
+    def pack_params(self, device):
+        """fp32 parameter block on ``device``.  Differentiable (torch.cat) when any
+        leaf requires grad and grad mode is on; otherwise cached on the leaves'
+        version counters so inference frames do not re-pack."""
+        leaves = self.leaves
+        if not leaves:
+            return torch.zeros(1, dtype=torch.float32, device=device)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in leaves)
+        if not needs_grad:
+            key = (str(device),) + tuple((p.data_ptr(), p._version, p.dtype) for p in leaves)
+            hit = self._packed.get("key") == key
+            if hit:
+                return self._packed["value"]
+        flat = torch.cat([p.reshape(-1).to(device=device, dtype=torch.float32) for p in leaves])
+        if not needs_grad:
+            self._packed = {"key": key, "value": flat.detach()}
+            return self._packed["value"]
+        return flat
+
+    def scene_struct(self, params, device):
+        """RmScene for a launch; keeps the referenced tensors alive via the return tuple."""
+        prog = self.device_program(device)
+        s = _abi.RmScene(program=prog.data_ptr(), params=params.data_ptr(), n_instr=self.n_instr,
+                         n_params=self.n_params, n_derived=self.n_derived,
+                         stack_floats=self.stack_floats, n_slots=self.n_slots)
+        return s, (prog, params)
+
+
+class _Emitter:
+    def __init__(self, offsets):
+        self.offsets = offsets        # id(param) -> float offset
+        self.code = []
+        self.n_slots = 0
+        self.n_derived = 0
+        self.depth = 0
+        self.max_depth = 0
+
+    def off(self, *params):
+        """Offset of the first parameter; the rest must follow contiguously."""
+        base = self.offsets[id(params[0])]
+        expect = base
+        for p in params:
+            if self.offsets[id(p)] != expect:
+                raise ValueError("scene parameters of one node are not contiguous in named_parameters() "
+                                 "order (shared nn.Parameter between fields of one node is not supported)")
+            expect += p.numel()
+        return base
+
+    def push(self, n):
+        self.depth += n
+        self.max_depth = max(self.max_depth, self.depth)
+
+    def pop(self, n):
+        self.depth -= n
+
+    def ins(self, op, off=0, a0=0, a1=0):
+        self.code.append((op, off, a0, a1))
+
+
+def _emit(node, em: _Emitter, n_params: int):
+    kind = getattr(node, "_rm_kind", None)
+    A = _abi
+    if kind == "sphere":
+        em.ins(A.OP_SPHERE, em.off(node.radius))
+    elif kind == "box":
+        em.ins(A.OP_BOX, em.off(node.halfsides))
+    elif kind == "plane":
+        em.ins(A.OP_PLANE)
+    elif kind == "line":
+        derived = n_params + em.n_derived
+        em.n_derived += 6
+        em.ins(A.OP_LINE, em.off(node.start, node.end, node.radius), derived)
+    elif kind == "disk":
+        em.ins(A.OP_DISK, em.off(node.radius))
+    elif kind == "torus":
+        em.ins(A.OP_TORUS, em.off(node.radius1, node.radius2))
+    elif kind == "affine":
+        off = em.off(node.translation, node.orientation)
+        em.ins(A.OP_AFFINE_PUSH, off)
+        em.push(_STACK_AFFINE)
+        _emit(node.sdf, em, n_params)
+        em.pop(_STACK_AFFINE)
+        em.ins(A.OP_AFFINE_POP, off)
+    elif kind in ("union", "smooth_union"):
+        kids = list(node.sdfs)
+        if not kids:
+            raise ValueError("SDFUnion / SDFSmoothUnion needs at least one child")
+        base = em.n_slots
+        em.n_slots += len(kids)
+        smooth = kind == "smooth_union"
+        koff = em.off(node.blend_k) if smooth else 0
+        em.ins(A.OP_SMOOTH_BEGIN if smooth else A.OP_UNION_BEGIN)
+        em.push(_STACK_SMOOTH if smooth else _STACK_UNION)
+        for i, child in enumerate(kids):
+            _emit(child, em, n_params)
+            em.ins(A.OP_FOLD_LSE if smooth else A.OP_FOLD_MIN, koff, base + i)
+        em.pop(_STACK_SMOOTH if smooth else _STACK_UNION)
+        em.ins(A.OP_SMOOTH_END if smooth else A.OP_UNION_END, koff, base, len(kids))
+    elif kind == "rounding":
+        _emit(node.sdf, em, n_params)
+        em.ins(A.OP_ROUND, em.off(node.rounding))
+    elif kind == "onion":
+        _emit(node.sdf, em, n_params)
+        slot = em.n_slots
+        em.n_slots += 1
+        em.ins(A.OP_ONION, em.off(node.radius), slot)
+    else:
+        raise TypeError(
+            f"{type(node).__name__} is not a ray_marching_amd SDF node; only the node types of "
+            "ray_marching_amd.scene (the reference's 6 primitives and 5 combinators) can be compiled "
+            "for the HIP kernels")
+
+
+def compile_scene(module: nn.Module) -> CompiledScene:
+    """Lower an SDF module tree.  Pure host logic (no GPU needed)."""
+    names, leaves, offsets, table = [], [], [], {}
+    cursor = 0
+    for name, p in module.named_parameters():
+        names.append(name)
+        leaves.append(p)
+        offsets.append(cursor)
+        table[id(p)] = cursor
+        cursor += p.numel()
+    n_params = cursor
+    em = _Emitter(table)
+    _emit(module, em, n_params)
+    program = np.asarray(em.code, dtype=np.int32).reshape(-1, 4)
+    rc = _abi.lib.rm_validate_program(program.ctypes.data, program.shape[0], n_params, em.n_derived,
+                                      em.max_depth, em.n_slots)
+    _abi.check(rc, "rm_validate_program")
+    signature = (tuple(map(tuple, program.tolist())), n_params, em.n_derived, em.max_depth, em.n_slots)
+    return CompiledScene(program=program, leaves=leaves, leaf_names=names, leaf_offsets=offsets,
+                         n_params=n_params, n_derived=em.n_derived, stack_floats=em.max_depth,
+                         n_slots=em.n_slots, signature=signature)
+
+
+def structure_key(module: nn.Module):
+    """Cheap key that changes when the tree topology or parameter identity changes."""
+    return tuple((type(m).__name__, id(m)) for m in module.modules()) + \
+        tuple(id(p) for p in module.parameters())
+
+
+def compiled_for(module: nn.Module) -> CompiledScene:
+    """Compile once per (module instance, topology) and cache on the module."""
+    key = structure_key(module)
+    cache = module.__dict__.get("_rm_compiled")
+    if cache is None or cache[0] != key:
+        cache = (key, compile_scene(module))
+        module.__dict__["_rm_compiled"] = cache
+    return cache[1]

@@ -1,0 +1,353 @@
+// rm_abi.hip -- C ABI (include/rm_abi.h) over the generic interpreter kernels.
+// Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC rm_abi.hip -o librm_hip.so
+#include "rm_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+constexpr int kMaxBlocks = 2048;        // persistent grid cap: 256 CUs x 8 blocks
+constexpr int kMaxBlocksBwd = 1024;     // also the partials row count
+constexpr size_t kLdsDefault = 64 * 1024;
+constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
+
+int check_scene(const RmScene* sc) {
+  if (!sc || !sc->program || (!sc->params && sc->n_params > 0))
+    return fail(RM_E_BADARG, "scene: null program/params");
+  if (sc->n_instr <= 0 || sc->n_instr > 4096 || sc->n_params < 0 || sc->n_derived < 0 ||
+      sc->stack_floats < 0 || sc->n_slots < 0)
+    return fail(RM_E_BADARG, "scene: bad sizes (n_instr=%d n_params=%d)", sc->n_instr, sc->n_params);
+  return RM_OK;
+}
+
+struct Launch {
+  int block;
+  size_t lds;
+};
+
+// LDS bytes of the generic path for a block of `block` threads.
+size_t lds_bytes(const RmScene& sc, int block, bool backward) {
+  size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
+  size_t per_thread = (size_t)sc.stack_floats + sc.n_slots + (backward ? sc.n_params + sc.n_derived : 0);
+  return 4 * (pb + 4 * (size_t)sc.n_instr + per_thread * (block + 1));
+}
+
+template <class K>
+int pick_launch(K kernel, const RmScene& sc, bool backward, int max_block, Launch* out) {
+  for (int block = max_block; block >= 64; block >>= 1) {
+    size_t b = lds_bytes(sc, block, backward);
+    if (b <= kLdsDefault) { *out = {block, b}; return RM_OK; }
+  }
+  size_t b = lds_bytes(sc, 64, backward);
+  if (b > kLdsMax) return fail(RM_E_TOO_LARGE, "scene needs %zu B of LDS per 64-ray block (max %zu)", b, kLdsMax);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  *out = {64, b};
+  return RM_OK;
+}
+
+int grid_for(int64_t tiles, int cap) {
+  if (tiles < 1) tiles = 1;
+  return (int)(tiles < cap ? tiles : cap);
+}
+
+int launched(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RM_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return RM_OK;
+}
+
+int reduce_partials(const RmScene& sc, const float* partials, int nblocks, float* grad_params, hipStream_t s) {
+  if (!grad_params) return RM_OK;
+  size_t lds = 4 * (size_t)(sc.n_params + sc.n_derived + 1);
+  rm::k_reduce_partials<<<1, 256, lds, s>>>(sc, partials, nblocks, grad_params);
+  return launched("k_reduce_partials");
+}
+
+using G = rm::GenericCfg;
+
+}  // namespace
+
+extern "C" {
+
+int rm_abi_version(void) { return RM_ABI_VERSION; }
+
+const char* rm_last_error(void) { return g_err; }
+
+int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
+  if (!scene) return 0;
+  (void)n;
+  return (int64_t)kMaxBlocksBwd * (scene->n_params + scene->n_derived);
+}
+
+int rm_sdf_forward(const RmScene* scene, const float* points, float* dist, int64_t n, void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (n < 0 || (n > 0 && (!points || !dist))) return fail(RM_E_BADARG, "rm_sdf_forward: null buffer");
+  if (n == 0) return RM_OK;
+  Launch L;
+  if (int e = pick_launch(rm::k_sdf_fwd<G>, *scene, false, 256, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
+  rm::k_sdf_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, dist, n);
+  return launched("k_sdf_fwd");
+}
+
+int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad_dist, float* grad_points,
+                    float* grad_params, float* partials, int64_t n, void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (n <= 0 || !points || !grad_dist || !partials) return fail(RM_E_BADARG, "rm_sdf_backward: null buffer / n<=0");
+  Launch L;
+  if (int e = pick_launch(rm::k_sdf_bwd<G>, *scene, true, 128, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  rm::k_sdf_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
+  if (int e = launched("k_sdf_bwd")) return e;
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+}
+
+int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, float* out_pos, float* traj,
+                     int32_t* nexec, int64_t n, int32_t steps, int32_t flags, void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (n < 0 || steps < 0 || (n > 0 && (!pos || !dirs || !out_pos))) return fail(RM_E_BADARG, "rm_march_forward: bad args");
+  if (n == 0) return RM_OK;
+  Launch L;
+  if (int e = pick_launch(rm::k_march_fwd<G>, *scene, false, 256, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
+  rm::k_march_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, pos, dirs, out_pos, traj, nexec, n, steps, flags);
+  return launched("k_march_fwd");
+}
+
+int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj, const int32_t* nexec,
+                      const float* grad_out, float* grad_pos, float* grad_dirs, float* grad_params,
+                      float* partials, int64_t n, int32_t steps, void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (n <= 0 || steps < 0 || !dirs || !grad_out || !partials || (steps > 0 && !traj))
+    return fail(RM_E_BADARG, "rm_march_backward: bad args");
+  Launch L;
+  if (int e = pick_launch(rm::k_march_bwd<G>, *scene, true, 128, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  rm::k_march_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, dirs, traj, nexec, grad_out, grad_pos, grad_dirs,
+                                                                   partials, n, steps);
+  if (int e = launched("k_march_bwd")) return e;
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+}
+
+int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* coords, float* normals,
+                       float* laplacian, int64_t n, void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (!tetra || n < 0 || (n > 0 && (!coords || !normals || !laplacian))) return fail(RM_E_BADARG, "rm_normals_forward: bad args");
+  if (n == 0) return RM_OK;
+  Launch L;
+  if (int e = pick_launch(rm::k_normals_fwd<G>, *scene, false, 256, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
+  rm::k_normals_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, normals, laplacian, n);
+  return launched("k_normals_fwd");
+}
+
+int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float* coords, const float* grad_normals,
+                        const float* grad_lap, float* grad_coords, float* grad_params, float* partials, int64_t n,
+                        void* stream) {
+  if (int e = check_scene(scene)) return e;
+  if (!tetra || n <= 0 || !coords || !partials) return fail(RM_E_BADARG, "rm_normals_backward: bad args");
+  Launch L;
+  if (int e = pick_launch(rm::k_normals_bwd<G>, *scene, true, 128, &L)) return e;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  rm::k_normals_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, grad_normals, grad_lap,
+                                                                     grad_coords, partials, n);
+  if (int e = launched("k_normals_bwd")) return e;
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+}
+
+int rm_camera_forward(const RmCamera* cam, const float* orientation, const float* translation, float* out_pos,
+                      float* out_dirs, float* out_frames, void* stream) {
+  if (!cam || !cam->ray_positions || !cam->ray_directions || !orientation || !translation || !out_pos || !out_dirs)
+    return fail(RM_E_BADARG, "rm_camera_forward: null buffer");
+  if (cam->num_cameras <= 0 || cam->num_cameras > 256 || cam->height <= 0 || cam->width <= 0)
+    return fail(RM_E_BADARG, "rm_camera_forward: bad camera shape");
+  int64_t n = (int64_t)cam->num_cameras * cam->height * cam->width;
+  int grid = grid_for((n + 255) / 256, kMaxBlocks);
+  rm::k_camera_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(*cam, orientation, translation, out_pos, out_dirs, out_frames);
+  return launched("k_camera_fwd");
+}
+
+static int check_render(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
+                        const float* translation, int32_t steps, int32_t row_begin, int32_t row_end) {
+  if (int e = check_scene(scene)) return e;
+  if (!cam || !tetra || !cam->ray_positions || !cam->ray_directions || !orientation || !translation)
+    return fail(RM_E_BADARG, "render: null camera / pose");
+  if (cam->num_cameras <= 0 || cam->height <= 0 || cam->width <= 0) return fail(RM_E_BADARG, "render: bad camera shape");
+  if (steps < 0 || row_begin < 0 || row_end > cam->height || row_begin >= row_end)
+    return fail(RM_E_BADARG, "render: bad steps/rows (%d, [%d,%d) of %d)", steps, row_begin, row_end, cam->height);
+  return RM_OK;
+}
+
+int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
+                      const float* translation, float* image, float* p_final, float* traj, int32_t* nexec,
+                      uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
+                      int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, void* stream) {
+  if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
+  if (!image) return fail(RM_E_BADARG, "rm_render_forward: null image");
+  if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_render_forward: mode %d not in 0..7", mode);
+  bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
+  if (global && !minmax) return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a minmax buffer", mode);
+  if ((mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN) && (!cmap || cmap_size <= 0))
+    return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a colormap", mode);
+  rm::RenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
+  a.orientation = orientation; a.translation = translation;
+  a.image = image; a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.minmax = minmax;
+  a.cmap = cmap; a.cmap_size = cmap_size;
+  a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
+  Launch L;
+  if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, 256, &L)) return e;
+  int64_t tiles;
+  {
+    const int W = cam->width, rows = row_end - row_begin;
+    if (flags & RM_FLAG_TILE8X8) {
+      int64_t waves = (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3);
+      int wpb = L.block >> 6;
+      tiles = (waves + wpb - 1) / wpb;
+    } else {
+      tiles = ((int64_t)cam->num_cameras * rows * W + L.block - 1) / L.block;
+    }
+  }
+  int grid = grid_for(tiles, kMaxBlocks);
+  rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  return launched("k_render_fwd");
+}
+
+int rm_minmax_init(uint32_t* minmax, void* stream) {
+  if (!minmax) return fail(RM_E_BADARG, "rm_minmax_init: null");
+  rm::k_minmax_init<<<1, 1, 0, (hipStream_t)stream>>>(minmax);
+  return launched("k_minmax_init");
+}
+
+int rm_minmax_decode(const uint32_t* minmax, float* lohi, void* stream) {
+  if (!minmax || !lohi) return fail(RM_E_BADARG, "rm_minmax_decode: null");
+  rm::k_minmax_decode<<<1, 1, 0, (hipStream_t)stream>>>(minmax, lohi);
+  return launched("k_minmax_decode");
+}
+
+int rm_minmax_encode(const float* lohi, uint32_t* minmax, void* stream) {
+  if (!minmax || !lohi) return fail(RM_E_BADARG, "rm_minmax_encode: null");
+  rm::k_minmax_encode<<<1, 1, 0, (hipStream_t)stream>>>(lohi, minmax);
+  return launched("k_minmax_encode");
+}
+
+int rm_shade_finish(float* image, int64_t n_pixels, const uint32_t* minmax, int32_t mode, void* stream) {
+  if (!image || !minmax || n_pixels < 0) return fail(RM_E_BADARG, "rm_shade_finish: bad args");
+  if (!(mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN))
+    return fail(RM_E_BADARG, "rm_shade_finish: mode %d has no second pass", mode);
+  if (n_pixels == 0) return RM_OK;
+  int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
+  rm::k_shade_finish<<<grid, 256, 0, (hipStream_t)stream>>>(image, n_pixels, minmax, mode);
+  return launched("k_shade_finish");
+}
+
+int rm_shade_forward(const float* px_coords, const float* orientation, const float* frames, const float* dirs,
+                     const float* coords, const float* normals, const float* lap, const float* dist, float* image,
+                     uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
+                     int64_t n_pixels, int64_t pixels_per_camera, void* stream) {
+  if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_shade_forward: mode %d not in 0..7", mode);
+  if (!image || n_pixels < 0 || pixels_per_camera <= 0) return fail(RM_E_BADARG, "rm_shade_forward: bad args");
+  const bool need_n = (mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL || mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
+  const bool need_v = (mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_VIGNETTE || mode == RM_MODE_TANGENT);
+  const bool need_q = (mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
+  const bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
+  if ((need_n && !normals) || (need_v && !dirs) || (need_q && (!orientation || !cmap || cmap_size <= 0)) ||
+      (mode == RM_MODE_DISTANCE && (!px_coords || !coords)) || (mode == RM_MODE_PROXIMITY && !dist) ||
+      (mode == RM_MODE_LAPLACIAN && !lap) || (mode == RM_MODE_VIGNETTE && !frames) || (global && !minmax))
+    return fail(RM_E_BADARG, "rm_shade_forward: an input required by mode %d is null", mode);
+  if (n_pixels == 0) return RM_OK;
+  rm::ShadeArgs a{px_coords, orientation, frames, dirs, coords, normals, lap, dist, image, minmax, cmap,
+                  cmap_size, mode, degree, n_pixels, pixels_per_camera};
+  int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
+  rm::k_shade_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return launched("k_shade_fwd");
+}
+
+int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
+                       const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
+                       const float* grad_image, float* grad_params, float* partials, int32_t mode, int32_t steps,
+                       int32_t row_begin, int32_t row_end, void* stream) {
+  if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
+  if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL))
+    return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (use modes 0 or 4)", mode);
+  if (!p_final || !grad_image || !partials || (steps > 0 && !traj)) return fail(RM_E_BADARG, "rm_render_backward: null buffer");
+  rm::RenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
+  a.orientation = orientation; a.translation = translation;
+  a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
+  a.grad_image = grad_image; a.partials = partials;
+  a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = 0;
+  Launch L;
+  if (int e = pick_launch(rm::k_render_bwd<G>, *scene, true, 128, &L)) return e;
+  int64_t n = (int64_t)cam->num_cameras * (row_end - row_begin) * cam->width;
+  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  rm::k_render_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  if (int e = launched("k_render_bwd")) return e;
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+}
+
+/* Host-side validation of a compiled program (host pointer).  The device copy a
+ * RmScene points at cannot be inspected without a synchronising copy, so the host
+ * compiler validates once here before uploading. */
+int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_params, int32_t n_derived,
+                        int32_t stack_floats, int32_t n_slots) {
+  if (!host_program || n_instr <= 0) return fail(RM_E_PROGRAM, "empty program");
+  static const int psize[RM_OP__COUNT] = {0, 1, 3, 0, 7, 1, 2, 7, 7, 0, 0, 0, 0, 1, 1, 1, 1};
+  int depth_f = 0, depth_b = 0, max_f = 0, max_b = 0, values = 0;
+  for (int i = 0; i < n_instr; ++i) {
+    const int32_t* w = host_program + 4 * i;
+    int op = w[0], off = w[1], a0 = w[2], a1 = w[3];
+    if (op <= RM_OP_END || op >= RM_OP__COUNT) return fail(RM_E_PROGRAM, "instr %d: bad opcode %d", i, op);
+    if (psize[op] && (off < 0 || off + psize[op] > n_params)) return fail(RM_E_PROGRAM, "instr %d: params out of range", i);
+    switch (op) {
+      case RM_OP_LINE:
+        if (a0 < n_params || a0 + 6 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: derived block out of range", i);
+        values++;
+        break;
+      case RM_OP_SPHERE: case RM_OP_BOX: case RM_OP_PLANE: case RM_OP_DISK: case RM_OP_TORUS:
+        values++;
+        break;
+      case RM_OP_AFFINE_PUSH: depth_f += 3; depth_b += 6; break;
+      case RM_OP_AFFINE_POP: depth_f -= 3; depth_b -= 6; break;
+      case RM_OP_UNION_BEGIN: depth_f += 1; depth_b += 2; break;
+      case RM_OP_SMOOTH_BEGIN: depth_b += 2; break;
+      case RM_OP_UNION_END: case RM_OP_SMOOTH_END:
+        if (a1 <= 0 || a0 < 0 || a0 + a1 > n_slots) return fail(RM_E_PROGRAM, "instr %d: slots out of range", i);
+        depth_f -= (op == RM_OP_UNION_END) ? 1 : 0; depth_b -= 2;
+        values++;
+        break;
+      case RM_OP_FOLD_MIN: case RM_OP_FOLD_LSE: case RM_OP_ONION:
+        if (a0 < 0 || a0 >= n_slots) return fail(RM_E_PROGRAM, "instr %d: slot out of range", i);
+        if (op != RM_OP_ONION) values--;
+        break;
+      default: break;
+    }
+    if (depth_f < 0 || depth_b < 0 || values < 0 || values > 1)
+      return fail(RM_E_PROGRAM, "instr %d: unbalanced program (value register holds %d values)", i, values);
+    if (depth_f > max_f) max_f = depth_f;
+    if (depth_b > max_b) max_b = depth_b;
+  }
+  if (depth_f != 0 || depth_b != 0) return fail(RM_E_PROGRAM, "unbalanced program at end");
+  if (values != 1) return fail(RM_E_PROGRAM, "program leaves %d values (expected 1)", values);
+  if (max_b > stack_floats || max_f > stack_floats) return fail(RM_E_PROGRAM, "stack_floats %d < needed %d", stack_floats, max_b);
+  return RM_OK;
+}
+
+}  // extern "C"

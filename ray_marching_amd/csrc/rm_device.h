@@ -1,0 +1,530 @@
+// rm_device.h -- device-side SDF evaluation for gfx950 (MI355X, wave64).
+//
+// One implementation of every scene-graph node (forward value and reverse-mode
+// VJP), written once as straight-line handlers over a small per-ray machine
+// state.  Two drivers run the handlers:
+//   * RuntimeProgram : a wave-uniform interpreter loop over a program staged in
+//     LDS (any scene, no recompilation);
+//   * StaticProgram  : the same handlers unrolled at compile time over a
+//     constexpr program (stack/tape become registers, scalar branches vanish).
+//
+// Arithmetic follows the reference's ATen CPU op stream operation by operation
+// (compile with -ffp-contract=off): products and sums round separately except
+// inside vector norms, where ATen's kernel is an FMA chain
+// fma(z,z,fma(y,y,x*x)) -- measured in this repo, see DESIGN.md "Numerics".
+// Comparisons are written so NaNs propagate the way torch's min/max/clamp/where
+// do.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rm_abi.h"
+
+namespace rm {
+
+// --------------------------------------------------------------------------
+// small vector type
+// --------------------------------------------------------------------------
+struct V3 {
+  float x, y, z;
+};
+
+#define RM_DEV __device__ __forceinline__
+
+RM_DEV V3 mk3(float x, float y, float z) { return V3{x, y, z}; }
+RM_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RM_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RM_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+RM_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// dot with torch's .mul().sum(-1) rounding: three rounded products, sequential adds.
+RM_DEV float dot_seq(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// quaternion.py:18-21 -- each product rounded, then the difference.
+RM_DEV V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
+RM_DEV float norm3(V3 a) { return __fsqrt_rn(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
+RM_DEV float norm2(float a, float b) { return __fsqrt_rn(__builtin_fmaf(b, b, a * a)); }
+// quaternion.py:55-72: V + w*t + qv x t, t = 2*(qv x V); summed as (y + w*t) + V.
+RM_DEV V3 qrot(V3 v, float w, V3 qv) {
+  V3 t = 2.0f * cross(qv, v);
+  V3 y = cross(qv, t);
+  return (y + w * t) + v;
+}
+
+// torch semantics helpers ---------------------------------------------------
+RM_DEV float t_relu_keep(float x) { return (x > 0.0f) ? x : 0.0f; }             // x.where(x > 0, 0)
+RM_DEV float t_clamp(float x, float lo, float hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }  // NaN passes
+RM_DEV float t_min(float acc, float d) { return (d < acc || d != d) ? d : acc; }  // NaN-propagating
+RM_DEV float t_max(float acc, float d) { return (d > acc || d != d) ? d : acc; }
+RM_DEV float sgn0(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+RM_DEV float uniform_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+RM_DEV int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// --------------------------------------------------------------------------
+// per-ray storage policies (evaluation stack + tape + gradient accumulators)
+// --------------------------------------------------------------------------
+// LDS columns: element i of this thread lives at base[i * stride]; conflict-free
+// because consecutive lanes hit consecutive banks.
+struct LdsStore {
+  float* base;
+  int stride;
+  RM_DEV float ld(int i) const { return base[i * stride]; }
+  RM_DEV void st(int i, float v) { base[i * stride] = v; }
+  RM_DEV void add(int i, float v) { base[i * stride] += v; }
+};
+
+// Registers: with a StaticProgram every index is a compile-time constant after
+// inlining, so SROA turns the array into VGPRs.
+template <int N>
+struct RegStore {
+  float r[N > 0 ? N : 1];
+  RM_DEV float ld(int i) const { return r[i]; }
+  RM_DEV void st(int i, float v) { r[i] = v; }
+  RM_DEV void add(int i, float v) { r[i] += v; }
+};
+
+// Parameter block view (LDS).  Values are wave-uniform; readfirstlane moves them
+// to SGPRs so they ride along as scalar operands.
+struct Params {
+  const float* p;
+  RM_DEV float operator[](int i) const { return uniform_f(p[i]); }
+  RM_DEV V3 v3(int i) const { return V3{uniform_f(p[i]), uniform_f(p[i + 1]), uniform_f(p[i + 2])}; }
+};
+
+// --------------------------------------------------------------------------
+// forward machine
+// --------------------------------------------------------------------------
+template <class Store>
+struct Fwd {
+  V3 p;        // query point in the current (innermost affine) frame
+  float d;     // value register: distance produced by the last node
+  float acc;   // running min of the innermost open SDFUnion
+  int sp;      // stack pointer (floats)
+  int tape0;   // index of tape slot 0 inside the store
+  Store* st;
+  bool record; // record every fold/onion input (needed by the reverse sweep)
+};
+
+template <class S>
+RM_DEV void fwd_op(S& s, Params P, int op, int off, int a0, int a1) {
+  switch (op) {
+    case RM_OP_SPHERE:  // |p| - r
+      s.d = norm3(s.p) - P[off];
+      break;
+    case RM_OP_BOX: {  // |relu(q)| + min(max(q),0), q = |p| - h
+      float qx = fabsf(s.p.x) - P[off], qy = fabsf(s.p.y) - P[off + 1], qz = fabsf(s.p.z) - P[off + 2];
+      float m = t_max(t_max(qx, qy), qz);
+      float nr = norm3(mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz)));
+      s.d = nr + ((m < 0.0f) ? m : 0.0f);
+    } break;
+    case RM_OP_PLANE:
+      s.d = s.p.x;
+      break;
+    case RM_OP_LINE: {  // capsule; derived block holds AB and AB/|AB|^2
+      V3 ab = P.v3(a0), abs_ = P.v3(a0 + 3);
+      V3 ap = s.p - P.v3(off);
+      float h = t_clamp(dot_seq(ap, abs_), 0.0f, 1.0f);
+      V3 w = mk3(h * ab.x - ap.x, h * ab.y - ap.y, h * ab.z - ap.z);
+      s.d = norm3(w) - P[off + 6];
+    } break;
+    case RM_OP_DISK: {  // axis x, radius in yz
+      float rd = norm2(s.p.y, s.p.z) - P[off];
+      s.d = norm2(s.p.x, t_relu_keep(rd));
+    } break;
+    case RM_OP_TORUS: {  // ring in xz
+      float ring = norm2(s.p.x, s.p.z) - P[off];
+      s.d = norm2(ring, s.p.y) - P[off + 1];
+    } break;
+    case RM_OP_AFFINE_PUSH: {  // child(rot(p - t, conj(q)))
+      s.st->st(s.sp, s.p.x); s.st->st(s.sp + 1, s.p.y); s.st->st(s.sp + 2, s.p.z);
+      s.sp += 3;
+      V3 t = P.v3(off);
+      s.p = qrot(s.p - t, P[off + 3], neg(P.v3(off + 4)));
+    } break;
+    case RM_OP_AFFINE_POP:
+      s.sp -= 3;
+      s.p = mk3(s.st->ld(s.sp), s.st->ld(s.sp + 1), s.st->ld(s.sp + 2));
+      break;
+    case RM_OP_UNION_BEGIN:
+      s.st->st(s.sp, s.acc); s.sp += 1;
+      s.acc = __builtin_inff();
+      break;
+    case RM_OP_FOLD_MIN:
+      if (s.record) s.st->st(s.tape0 + a0, s.d);
+      s.acc = t_min(s.acc, s.d);
+      break;
+    case RM_OP_UNION_END:
+      s.d = s.acc;
+      s.sp -= 1; s.acc = s.st->ld(s.sp);
+      break;
+    case RM_OP_SMOOTH_BEGIN:
+      break;
+    case RM_OP_FOLD_LSE:  // children are kept on the tape; the reduction is two-pass like torch.logsumexp
+      s.st->st(s.tape0 + a0, s.d);
+      break;
+    case RM_OP_SMOOTH_END: {  // -logsumexp(-k d)/k : max, sum exp(x - max), log + max, / (-k)
+      float nk = -P[off];
+      float m = -__builtin_inff();
+      for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
+      float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
+      float sum = 0.0f;
+      for (int i = 0; i < a1; ++i) sum = sum + expf(s.st->ld(s.tape0 + a0 + i) * nk - mm);
+      s.d = (logf(sum) + mm) / nk;
+    } break;
+    case RM_OP_ROUND:
+      s.d = s.d - P[off];
+      break;
+    case RM_OP_ONION:
+      if (s.record) s.st->st(s.tape0 + a0, s.d);
+      s.d = fabsf(s.d) - P[off];
+      break;
+    default:
+      break;
+  }
+}
+
+// --------------------------------------------------------------------------
+// reverse machine: walks the program backwards.  `g` is dL/d(value register) at
+// the current program point, `gp` accumulates dL/d(point) in the current frame.
+// Gradient accumulators live in the store at index acc0 + parameter offset
+// (raw parameters first, derived constants after them).
+// --------------------------------------------------------------------------
+template <class Store>
+struct Bwd {
+  V3 p;
+  V3 gp;
+  float g;
+  float gframe;  // upstream of the innermost open union / smooth-union
+  float fval;    // union: winning slot (as float); smooth-union: logsumexp value L
+  int sp;
+  int tape0;
+  int acc0;
+  Store* st;
+};
+
+template <class S>
+RM_DEV V3 safe_unit_scaled(V3 w, float n, float g) {
+  // torch norm backward: self * (grad / norm), 0 where norm == 0.
+  float s = (n == 0.0f) ? 0.0f : g / n;
+  return mk3(w.x * s, w.y * s, w.z * s);
+}
+
+template <class S>
+RM_DEV void bwd_op(S& s, Params P, int op, int off, int a0, int a1) {
+  const int A = s.acc0;
+  switch (op) {
+    case RM_OP_SPHERE: {
+      float n = norm3(s.p);
+      s.gp = s.gp + safe_unit_scaled<S>(s.p, n, s.g);
+      s.st->add(A + off, -s.g);
+    } break;
+    case RM_OP_BOX: {
+      float qx = fabsf(s.p.x) - P[off], qy = fabsf(s.p.y) - P[off + 1], qz = fabsf(s.p.z) - P[off + 2];
+      float m = t_max(t_max(qx, qy), qz);
+      V3 r = mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz));
+      float nr = norm3(r);
+      V3 gr = safe_unit_scaled<S>(r, nr, s.g);
+      // where(q > 0): gradient only where q > 0 ; max(dim): first index attaining the max
+      float gm = (m < 0.0f) ? s.g : 0.0f;
+      int arg = (qx == m) ? 0 : ((qy == m) ? 1 : 2);
+      float gqx = ((qx > 0.0f) ? gr.x : 0.0f) + ((arg == 0) ? gm : 0.0f);
+      float gqy = ((qy > 0.0f) ? gr.y : 0.0f) + ((arg == 1) ? gm : 0.0f);
+      float gqz = ((qz > 0.0f) ? gr.z : 0.0f) + ((arg == 2) ? gm : 0.0f);
+      s.gp = s.gp + mk3(gqx * sgn0(s.p.x), gqy * sgn0(s.p.y), gqz * sgn0(s.p.z));
+      s.st->add(A + off, -gqx); s.st->add(A + off + 1, -gqy); s.st->add(A + off + 2, -gqz);
+    } break;
+    case RM_OP_PLANE:
+      s.gp.x += s.g;
+      break;
+    case RM_OP_LINE: {
+      V3 ab = P.v3(a0), abs_ = P.v3(a0 + 3);
+      V3 ap = s.p - P.v3(off);
+      float h0 = dot_seq(ap, abs_);
+      float h = t_clamp(h0, 0.0f, 1.0f);
+      V3 w = mk3(h * ab.x - ap.x, h * ab.y - ap.y, h * ab.z - ap.z);
+      float nw = norm3(w);
+      V3 gw = safe_unit_scaled<S>(w, nw, s.g);
+      float gh = (gw.x * ab.x + gw.y * ab.y) + gw.z * ab.z;
+      float gh0 = (h0 >= 0.0f && h0 <= 1.0f) ? gh : 0.0f;  // clamp passes grad on the closed interval
+      V3 gap = mk3(gh0 * abs_.x - gw.x, gh0 * abs_.y - gw.y, gh0 * abs_.z - gw.z);
+      s.gp = s.gp + gap;
+      s.st->add(A + off, -gap.x); s.st->add(A + off + 1, -gap.y); s.st->add(A + off + 2, -gap.z);  // start
+      s.st->add(A + off + 6, -s.g);                                                               // radius
+      s.st->add(A + a0, h * gw.x); s.st->add(A + a0 + 1, h * gw.y); s.st->add(A + a0 + 2, h * gw.z);           // dAB
+      s.st->add(A + a0 + 3, gh0 * ap.x); s.st->add(A + a0 + 4, gh0 * ap.y); s.st->add(A + a0 + 5, gh0 * ap.z);  // d(AB/|AB|^2)
+    } break;
+    case RM_OP_DISK: {
+      float a = norm2(s.p.y, s.p.z);
+      float rd = a - P[off];
+      float c = t_relu_keep(rd);
+      float d = norm2(s.p.x, c);
+      float sc = (d == 0.0f) ? 0.0f : s.g / d;
+      float gc = c * sc;
+      float grd = (rd > 0.0f) ? gc : 0.0f;
+      float sa = (a == 0.0f) ? 0.0f : grd / a;
+      s.gp = s.gp + mk3(s.p.x * sc, s.p.y * sa, s.p.z * sa);
+      s.st->add(A + off, -grd);
+    } break;
+    case RM_OP_TORUS: {
+      float a = norm2(s.p.x, s.p.z);
+      float ring = a - P[off];
+      float d0 = norm2(ring, s.p.y);
+      float sc = (d0 == 0.0f) ? 0.0f : s.g / d0;
+      float gring = ring * sc;
+      float sa = (a == 0.0f) ? 0.0f : gring / a;
+      s.gp = s.gp + mk3(s.p.x * sa, s.p.y * sc, s.p.z * sa);
+      s.st->add(A + off, -gring);
+      s.st->add(A + off + 1, -s.g);
+    } break;
+    case RM_OP_AFFINE_POP: {  // reverse order: enter the child frame
+      s.st->st(s.sp, s.p.x); s.st->st(s.sp + 1, s.p.y); s.st->st(s.sp + 2, s.p.z);
+      s.st->st(s.sp + 3, s.gp.x); s.st->st(s.sp + 4, s.gp.y); s.st->st(s.sp + 5, s.gp.z);
+      s.sp += 6;
+      s.p = qrot(s.p - P.v3(off), P[off + 3], neg(P.v3(off + 4)));
+      s.gp = mk3(0.0f, 0.0f, 0.0f);
+    } break;
+    case RM_OP_AFFINE_PUSH: {  // reverse order: leave the child frame, pull gp back
+      V3 gl = s.gp;
+      s.sp -= 6;
+      V3 po = mk3(s.st->ld(s.sp), s.st->ld(s.sp + 1), s.st->ld(s.sp + 2));
+      V3 gpo = mk3(s.st->ld(s.sp + 3), s.st->ld(s.sp + 4), s.st->ld(s.sp + 5));
+      float w = P[off + 3];
+      V3 u = neg(P.v3(off + 4));
+      V3 v = po - P.v3(off);
+      V3 t = 2.0f * cross(u, v);
+      // local = v + w t + u x t
+      V3 ugl = cross(u, gl);
+      V3 gv = (gl + 2.0f * cross(u, ugl)) - (2.0f * w) * ugl;   // J_v^T gl
+      float gw = (gl.x * t.x + gl.y * t.y) + gl.z * t.z;
+      V3 gt = w * gl + cross(gl, u);
+      V3 gu = cross(t, gl) + 2.0f * cross(v, gt);
+      s.st->add(A + off, -gv.x); s.st->add(A + off + 1, -gv.y); s.st->add(A + off + 2, -gv.z);
+      s.st->add(A + off + 3, gw);
+      s.st->add(A + off + 4, -gu.x); s.st->add(A + off + 5, -gu.y); s.st->add(A + off + 6, -gu.z);
+      s.p = po;
+      s.gp = gpo + gv;
+    } break;
+    case RM_OP_UNION_END: {  // reverse: open the frame; find the winner (first index on ties)
+      s.st->st(s.sp, s.gframe); s.st->st(s.sp + 1, s.fval); s.sp += 2;
+      float m = __builtin_inff();
+      for (int i = 0; i < a1; ++i) m = t_min(m, s.st->ld(s.tape0 + a0 + i));
+      int win = a0 + a1 - 1;
+      for (int i = a1 - 1; i >= 0; --i) {
+        float di = s.st->ld(s.tape0 + a0 + i);
+        if (di == m || (m != m && di != di)) win = a0 + i;
+      }
+      s.gframe = s.g;
+      s.fval = (float)win;
+    } break;
+    case RM_OP_FOLD_MIN:
+      s.g = ((float)a0 == s.fval) ? s.gframe : 0.0f;
+      break;
+    case RM_OP_UNION_BEGIN:
+      s.sp -= 2; s.gframe = s.st->ld(s.sp); s.fval = s.st->ld(s.sp + 1);
+      break;
+    case RM_OP_SMOOTH_END: {
+      s.st->st(s.sp, s.gframe); s.st->st(s.sp + 1, s.fval); s.sp += 2;
+      float k = P[off];
+      float nk = -k;
+      float m = -__builtin_inff();
+      for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
+      float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
+      float sum = 0.0f;
+      for (int i = 0; i < a1; ++i) sum = sum + expf(s.st->ld(s.tape0 + a0 + i) * nk - mm);
+      float L = logf(sum) + mm;
+      s.gframe = s.g;
+      s.fval = L;
+      // out = L / (-k): d out / dk through the division
+      s.st->add(A + off, s.g * L / (k * k));
+    } break;
+    case RM_OP_FOLD_LSE: {
+      float k = P[off];
+      float di = s.st->ld(s.tape0 + a0);
+      float w = expf(di * (-k) - s.fval);   // softmax weight of this child
+      s.g = s.gframe * w;
+      s.st->add(A + off, (s.gframe / k) * w * di);
+    } break;
+    case RM_OP_SMOOTH_BEGIN:
+      s.sp -= 2; s.gframe = s.st->ld(s.sp); s.fval = s.st->ld(s.sp + 1);
+      break;
+    case RM_OP_ROUND:
+      s.st->add(A + off, -s.g);
+      break;
+    case RM_OP_ONION: {
+      s.st->add(A + off, -s.g);
+      s.g = s.g * sgn0(s.st->ld(s.tape0 + a0));
+    } break;
+    default:
+      break;
+  }
+}
+
+// --------------------------------------------------------------------------
+// program drivers
+// --------------------------------------------------------------------------
+struct Ins {
+  int op, off, a0, a1;
+};
+
+// Interpreter over a program staged in LDS; instruction words are wave-uniform.
+struct RuntimeProgram {
+  const int4* code;  // LDS
+  int n;
+  template <class S>
+  RM_DEV void forward(S& s, Params P) const {
+    for (int pc = 0; pc < n; ++pc) {
+      int4 w = code[pc];
+      fwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
+    }
+  }
+  template <class S>
+  RM_DEV void backward(S& s, Params P) const {
+    for (int pc = n - 1; pc >= 0; --pc) {
+      int4 w = code[pc];
+      bwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
+    }
+  }
+};
+
+// Compile-time program: Code::code[] is constexpr, recursion unrolls it.
+template <class Code>
+struct StaticProgram {
+  template <int PC, class S>
+  RM_DEV void fwd_from(S& s, Params P) const {
+    if constexpr (PC < Code::n) {
+      constexpr Ins i = Code::code[PC];
+      fwd_op(s, P, i.op, i.off, i.a0, i.a1);
+      fwd_from<PC + 1>(s, P);
+    }
+  }
+  template <int PC, class S>
+  RM_DEV void bwd_from(S& s, Params P) const {
+    if constexpr (PC >= 0) {
+      constexpr Ins i = Code::code[PC];
+      bwd_op(s, P, i.op, i.off, i.a0, i.a1);
+      bwd_from<PC - 1>(s, P);
+    }
+  }
+  template <class S>
+  RM_DEV void forward(S& s, Params P) const { fwd_from<0>(s, P); }
+  template <class S>
+  RM_DEV void backward(S& s, Params P) const { bwd_from<Code::n - 1>(s, P); }
+};
+
+// Scene evaluation context shared by all kernels of one block.
+template <class Prog, class Store>
+struct Scene {
+  Prog prog;
+  Params P;
+  Store* st;
+  int tape0;   // store index of tape slot 0 (= stack_floats)
+  int acc0;    // store index of gradient accumulator 0 (= stack_floats + n_slots)
+
+  RM_DEV float eval(V3 p, bool record = false) const {
+    Fwd<Store> s;
+    s.p = p; s.d = 0.0f; s.acc = __builtin_inff(); s.sp = 0; s.tape0 = tape0; s.st = st; s.record = record;
+    prog.forward(s, P);
+    return s.d;
+  }
+  // VJP at point p with upstream g: returns dL/dp, adds parameter grads into the accumulators.
+  RM_DEV V3 vjp(V3 p, float g) const {
+    Fwd<Store> f;
+    f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
+    prog.forward(f, P);
+    Bwd<Store> b;
+    b.p = p; b.gp = mk3(0.0f, 0.0f, 0.0f); b.g = g; b.gframe = 0.0f; b.fval = 0.0f;
+    b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st;
+    prog.backward(b, P);
+    return b.gp;
+  }
+};
+
+// --------------------------------------------------------------------------
+// LDS staging of the scene block: raw parameters, then derived constants.
+// Derived constants (capsule AB and AB/|AB|^2, primitives.py:52-54) are
+// computed once per block instead of once per evaluation.
+// --------------------------------------------------------------------------
+RM_DEV void stage_scene(const RmScene& sc, float* s_params, int4* s_prog) {
+  for (int i = threadIdx.x; i < sc.n_params; i += blockDim.x) s_params[i] = sc.params[i];
+  const int4* gprog = reinterpret_cast<const int4*>(sc.program);
+  for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) s_prog[i] = gprog[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) {
+    int4 w = s_prog[i];
+    if (w.x == RM_OP_LINE) {
+      const float* a = s_params + w.y;
+      float abx = a[3] - a[0], aby = a[4] - a[1], abz = a[5] - a[2];
+      float len2 = (abx * abx + aby * aby) + abz * abz;  // AB.pow(2).sum(-1)
+      float* dst = s_params + w.z;
+      dst[0] = abx; dst[1] = aby; dst[2] = abz;
+      dst[3] = abx / len2; dst[4] = aby / len2; dst[5] = abz / len2;
+    }
+  }
+  __syncthreads();
+}
+
+// --------------------------------------------------------------------------
+// camera, normals, shaders
+// --------------------------------------------------------------------------
+struct Pose {
+  float w;
+  V3 qv;
+  V3 t;
+};
+
+RM_DEV V3 load3(const float* base, int64_t i) {
+  const float* q = base + 3 * i;
+  return V3{q[0], q[1], q[2]};
+}
+RM_DEV void store3(float* base, int64_t i, V3 v) {
+  float* q = base + 3 * i;
+  q[0] = v.x; q[1] = v.y; q[2] = v.z;
+}
+
+struct Tetra {
+  V3 o[4];
+  float inv[9];
+  float lap_scale;
+};
+
+RM_DEV Tetra load_tetra(const RmTetra& t) {
+  Tetra r;
+  for (int k = 0; k < 4; ++k) r.o[k] = mk3(t.offsets[3 * k], t.offsets[3 * k + 1], t.offsets[3 * k + 2]);
+  for (int k = 0; k < 9; ++k) r.inv[k] = t.inverse[k];
+  r.lap_scale = t.lap_scale;
+  return r;
+}
+
+// SDFNormals.forward (ray_marching.py:115-125).
+template <class SceneT>
+RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre, V3& n, float& lap) {
+  float f0 = sc.eval(p + T.o[0]);
+  float f1 = sc.eval(p + T.o[1]);
+  float f2 = sc.eval(p + T.o[2]);
+  float f3 = sc.eval(p + T.o[3]);
+  float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
+  V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
+             (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
+             (T.inv[6] * d1 + T.inv[7] * d2) + T.inv[8] * d3);
+  float nu = norm3(u);              // F.normalize(eps=0): u / |u|, 0/0 = NaN like the reference
+  n = mk3(u.x / nu, u.y / nu, u.z / nu);
+  float mean = (((f0 + f1) + f2) + f3) / 4.0f;
+  lap = (centre - mean) * T.lap_scale;
+}
+
+// monotone float <-> uint map for atomic min/max
+RM_DEV uint32_t f2ord(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+RM_DEV float ord2f(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __builtin_bit_cast(float, u);
+}
+
+}  // namespace rm

@@ -1,0 +1,723 @@
+// rm_kernels.h -- gfx950 kernels over the scene machine of rm_device.h.
+//
+// Every kernel is a template over a configuration `Cfg` that says how the
+// scene program is driven (RuntimeProgram interpreter + LDS store, or a
+// StaticProgram + register store).  The generic library instantiates them with
+// GenericCfg; per-scene specialisations (rm_spec.hip) instantiate the same
+// kernels with a StaticCfg.
+//
+// Launch shape: one ray per lane, persistent blocks that stride over 'tiles' of
+// blockDim rays; lanes past the end of the ray list keep executing on a clamped
+// index (so wave-wide votes and scalar reads stay well defined) and only their
+// stores are masked.
+#pragma once
+
+#include "rm_device.h"
+
+namespace rm {
+
+// ---------------------------------------------------------------------------
+// configurations
+// ---------------------------------------------------------------------------
+// Dynamic LDS layout of the generic path:
+//   [ params + derived | program (int4) | per-thread store columns ]
+struct GenericCfg {
+  using Store = LdsStore;
+  using Prog = RuntimeProgram;
+  using SceneT = Scene<Prog, Store>;
+  static constexpr bool kStatic = false;
+
+  // returns the scene context; `store` must outlive it
+  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
+    int pb = (sc.n_params + sc.n_derived + 3) & ~3;
+    float* s_params = smem;
+    int4* s_prog = reinterpret_cast<int4*>(smem + pb);
+    float* s_store = smem + pb + 4 * sc.n_instr;
+    stage_scene(sc, s_params, s_prog);
+    store.base = s_store + threadIdx.x;
+    store.stride = blockDim.x + 1;
+    SceneT s;
+    s.prog.code = s_prog; s.prog.n = sc.n_instr;
+    s.P.p = s_params;
+    s.st = &store;
+    s.tape0 = sc.stack_floats;
+    s.acc0 = sc.stack_floats + sc.n_slots;
+    return s;
+  }
+};
+
+// Compile-time scene: Code supplies n, code[], n_params, n_derived, stack_floats, n_slots.
+template <class Code>
+struct StaticCfg {
+  static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_derived;
+  using Store = RegStore<kStoreN>;
+  using Prog = StaticProgram<Code>;
+  using SceneT = Scene<Prog, Store>;
+  static constexpr bool kStatic = true;
+
+  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
+    // the parameter block is still staged through LDS (raw + derived), the program is not
+    float* s_params = smem;
+    for (int i = threadIdx.x; i < Code::n_params; i += blockDim.x) s_params[i] = sc.params[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < Code::n; ++i) {
+        if (Code::code[i].op == RM_OP_LINE) {
+          const float* a = s_params + Code::code[i].off;
+          float abx = a[3] - a[0], aby = a[4] - a[1], abz = a[5] - a[2];
+          float len2 = (abx * abx + aby * aby) + abz * abz;
+          float* dst = s_params + Code::code[i].a0;
+          dst[0] = abx; dst[1] = aby; dst[2] = abz;
+          dst[3] = abx / len2; dst[4] = aby / len2; dst[5] = abz / len2;
+        }
+      }
+    }
+    __syncthreads();
+    SceneT s;
+    s.P.p = s_params;
+    s.st = &store;
+    s.tape0 = Code::stack_floats;
+    s.acc0 = Code::stack_floats + Code::n_slots;
+    return s;
+  }
+};
+
+extern __shared__ __attribute__((aligned(16))) float rm_smem[];
+
+// ---------------------------------------------------------------------------
+// gradient accumulators: zero at start, block-reduce into partials at the end
+// ---------------------------------------------------------------------------
+template <class SceneT>
+RM_DEV void zero_accumulators(const SceneT& sc, int n_acc) {
+  for (int i = 0; i < n_acc; ++i) sc.st->st(sc.acc0 + i, 0.0f);
+}
+
+// partials[blockIdx.x][n_acc]: deterministic (fixed lane order) sum over the block.
+template <class Cfg>
+RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float* partials, float* smem_scratch) {
+  if constexpr (!Cfg::kStatic) {
+    __syncthreads();
+    // LDS columns: element i of thread t at base[i*stride + t]
+    const float* col0 = sc.st->base - threadIdx.x;
+    int stride = sc.st->stride;
+    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
+      const float* row = col0 + (int64_t)(sc.acc0 + i) * stride;
+      float sum = 0.0f;
+      for (int t = 0; t < (int)blockDim.x; ++t) sum += row[t];
+      partials[(int64_t)blockIdx.x * n_acc + i] = sum;
+    }
+  } else {
+    // registers: butterfly over the wave, then waves through LDS scratch
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    for (int i = 0; i < n_acc; ++i) {
+      float v = sc.st->ld(sc.acc0 + i);
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) smem_scratch[wave * n_acc + i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
+      float sum = 0.0f;
+      for (int w = 0; w < nw; ++w) sum += smem_scratch[w * n_acc + i];
+      partials[(int64_t)blockIdx.x * n_acc + i] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// scene(query) forward / backward
+// ---------------------------------------------------------------------------
+template <class Cfg>
+__global__ void k_sdf_fwd(RmScene sc, const float* __restrict__ pts, float* __restrict__ dist, int64_t n) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    float d = scene.eval(load3(pts, ic));
+    if (live) dist[i] = d;
+  }
+}
+
+template <class Cfg>
+__global__ void k_sdf_bwd(RmScene sc, const float* __restrict__ pts, const float* __restrict__ gd,
+                          float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  const int n_acc = sc.n_params + sc.n_derived;
+  zero_accumulators(scene, n_acc);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    float g = live ? gd[ic] : 0.0f;
+    V3 gp = scene.vjp(load3(pts, ic), g);
+    if (live && gpts) store3(gpts, i, gp);
+  }
+  flush_accumulators<Cfg>(scene, n_acc, partials, rm_smem + ((sc.n_params + sc.n_derived + 3) & ~3));
+}
+
+// ---------------------------------------------------------------------------
+// march
+// ---------------------------------------------------------------------------
+RM_DEV bool same_bits(V3 a, V3 b) {
+  return (__builtin_bit_cast(int, a.x) == __builtin_bit_cast(int, b.x)) &
+         (__builtin_bit_cast(int, a.y) == __builtin_bit_cast(int, b.y)) &
+         (__builtin_bit_cast(int, a.z) == __builtin_bit_cast(int, b.z));
+}
+
+// SDFMarcher.forward (ray_marching.py:78-84): p <- f(p)*v + p, `steps` times.
+// Early-out (bit-exact): the march map is a pure function of p, so once
+// p_{i+1} == p_i (fixed point) or p_{i+1} == p_{i-1} (2-cycle) bitwise, every later
+// iterate is known; the wave leaves when ALL its rays are in that state.  With a
+// trajectory being recorded only the fixed-point exit is taken (p_j = p_final for
+// j >= nexec).
+template <class SceneT>
+RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* traj, int64_t traj_stride,
+                int64_t ray, bool live, int& nexec) {
+  V3 prev = p;
+  nexec = steps;
+  for (int i = 0; i < steps; ++i) {
+    if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
+    float f = scene.eval(p);
+    V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
+    if (early) {
+      bool fixed = same_bits(pn, p);
+      bool settled = traj ? fixed : (fixed | same_bits(pn, prev));
+      if (__all(settled)) {
+        int remaining = steps - (i + 1);
+        nexec = i + 1;
+        return (remaining & 1) ? p : pn;  // fixed rays: p == pn; 2-cycles: parity picks the phase
+      }
+    }
+    prev = p;
+    p = pn;
+  }
+  return p;
+}
+
+template <class Cfg>
+__global__ void k_march_fwd(RmScene sc, const float* __restrict__ pos, const float* __restrict__ dirs,
+                            float* __restrict__ out, float* __restrict__ traj, int32_t* __restrict__ nexec_out,
+                            int64_t n, int steps, int flags) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    int nexec;
+    V3 p = march(scene, load3(pos, ic), load3(dirs, ic), steps, flags & RM_FLAG_EARLY_OUT, traj, n, ic, live, nexec);
+    if (live) {
+      store3(out, i, p);
+      if (nexec_out) nexec_out[i] = nexec;
+    }
+  }
+}
+
+// Reverse sweep of the march: lambda_i = lambda_{i+1} + (lambda_{i+1}.v) grad_p f(p_i),
+// dL/dtheta += (lambda_{i+1}.v) df/dtheta(p_i), dL/dv += f(p_i) lambda_{i+1}.
+template <class SceneT>
+RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
+                        int64_t ray, int nexec, int steps, V3* gv) {
+  for (int i = steps - 1; i >= 0; --i) {
+    V3 p = (i < nexec) ? load3(traj + 3 * (int64_t)i * traj_stride, ray) : p_final;
+    float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+    if (gv) {
+      float f = scene.eval(p);
+      *gv = *gv + f * lam;
+    }
+    lam = lam + scene.vjp(p, gf);
+  }
+  return lam;
+}
+
+template <class Cfg>
+__global__ void k_march_bwd(RmScene sc, const float* __restrict__ dirs, const float* __restrict__ traj,
+                            const int32_t* __restrict__ nexec, const float* __restrict__ gout,
+                            float* __restrict__ gpos, float* __restrict__ gdirs, float* __restrict__ partials,
+                            int64_t n, int steps) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  const int n_acc = sc.n_params + sc.n_derived;
+  zero_accumulators(scene, n_acc);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    V3 lam = live ? load3(gout, ic) : mk3(0.0f, 0.0f, 0.0f);
+    V3 v = load3(dirs, ic);
+    V3 gv = mk3(0.0f, 0.0f, 0.0f);
+    // With a trajectory recorded the forward leaves early only on a bitwise fixed point,
+    // so every iterate from nexec-1 on equals the last stored one.
+    int ne = nexec ? nexec[ic] : steps;
+    V3 pf = (ne > 0) ? load3(traj + 3 * (int64_t)(ne - 1) * n, ic) : mk3(0.0f, 0.0f, 0.0f);
+    lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs ? &gv : nullptr);
+    if (live) {
+      if (gpos) store3(gpos, i, lam);
+      if (gdirs) store3(gdirs, i, gv);
+    }
+  }
+  flush_accumulators<Cfg>(scene, n_acc, partials, rm_smem + ((sc.n_params + sc.n_derived + 3) & ~3));
+}
+
+// ---------------------------------------------------------------------------
+// normals
+// ---------------------------------------------------------------------------
+template <class Cfg>
+__global__ void k_normals_fwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts, float* __restrict__ nrm,
+                              float* __restrict__ lap, int64_t n) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  Tetra T = load_tetra(tetra);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    V3 p = load3(pts, ic);
+    float c = scene.eval(p);
+    V3 nn; float ll;
+    normals_forward(scene, T, p, c, nn, ll);
+    if (live) {
+      store3(nrm, i, nn);
+      lap[i] = ll;
+    }
+  }
+}
+
+// VJP of normals_forward.  gn: dL/dn, gl: dL/dlap.  Returns dL/dp.
+template <class SceneT>
+RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float gl, bool need_lap) {
+  float f0 = sc.eval(p + T.o[0]);
+  float f1 = sc.eval(p + T.o[1]);
+  float f2 = sc.eval(p + T.o[2]);
+  float f3 = sc.eval(p + T.o[3]);
+  float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
+  V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
+             (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
+             (T.inv[6] * d1 + T.inv[7] * d2) + T.inv[8] * d3);
+  float nu = norm3(u);
+  V3 n = mk3(u.x / nu, u.y / nu, u.z / nu);
+  // n = u / |u|  ->  g_u = (g_n - n (n.g_n)) / |u|
+  float ng = (n.x * gn.x + n.y * gn.y) + n.z * gn.z;
+  V3 gu = mk3((gn.x - n.x * ng) / nu, (gn.y - n.y * ng) / nu, (gn.z - n.z * ng) / nu);
+  float g1 = (T.inv[0] * gu.x + T.inv[3] * gu.y) + T.inv[6] * gu.z;
+  float g2 = (T.inv[1] * gu.x + T.inv[4] * gu.y) + T.inv[7] * gu.z;
+  float g3 = (T.inv[2] * gu.x + T.inv[5] * gu.y) + T.inv[8] * gu.z;
+  float g0 = -((g1 + g2) + g3);
+  V3 gp = mk3(0.0f, 0.0f, 0.0f);
+  if (need_lap) {  // lap = (f(p) - mean(taps)) * scale
+    float gs = gl * T.lap_scale;
+    float gm = -gs / 4.0f;
+    g0 += gm; g1 += gm; g2 += gm; g3 += gm;
+    gp = gp + sc.vjp(p, gs);
+  }
+  gp = gp + sc.vjp(p + T.o[0], g0);
+  gp = gp + sc.vjp(p + T.o[1], g1);
+  gp = gp + sc.vjp(p + T.o[2], g2);
+  gp = gp + sc.vjp(p + T.o[3], g3);
+  return gp;
+}
+
+template <class Cfg>
+__global__ void k_normals_bwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts,
+                              const float* __restrict__ gn, const float* __restrict__ gl,
+                              float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(sc, rm_smem, store);
+  const int n_acc = sc.n_params + sc.n_derived;
+  zero_accumulators(scene, n_acc);
+  Tetra T = load_tetra(tetra);
+  int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    int64_t ic = live ? i : n - 1;
+    V3 g = (gn && live) ? load3(gn, ic) : mk3(0.0f, 0.0f, 0.0f);
+    float gls = (gl && live) ? gl[ic] : 0.0f;
+    V3 gp = normals_backward(scene, T, load3(pts, ic), g, gls, gl != nullptr);
+    if (live && gpts) store3(gpts, i, gp);
+  }
+  flush_accumulators<Cfg>(scene, n_acc, partials, rm_smem + ((sc.n_params + sc.n_derived + 3) & ~3));
+}
+
+// ---------------------------------------------------------------------------
+// fused frame: camera -> march -> distance -> normals -> shader
+// ---------------------------------------------------------------------------
+struct RenderArgs {
+  RmScene scene;
+  RmCamera cam;
+  RmTetra tetra;
+  const float* orientation;  // [N,4]
+  const float* translation;  // [N,3]
+  float* image;              // [N,rows,W,3]
+  float* p_final;            // nullable
+  float* traj;               // nullable [steps, R, 3]
+  int32_t* nexec;            // nullable
+  uint32_t* minmax;          // nullable
+  const float* cmap;         // nullable
+  int32_t cmap_size;
+  int32_t mode, degree, steps, row_begin, row_end, flags;
+  // backward only
+  const float* grad_image;
+  float* partials;
+};
+
+// ray index of this lane inside the row band: R = N * rows * W rays, local index li.
+// With RM_FLAG_TILE8X8 the 64 lanes of a wave cover an 8x8 pixel tile (better
+// convergence coherence for the wave-uniform early-out); otherwise 64 pixels of a row.
+RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t tile, int& cam, int& row, int& col) {
+  const int W = a.cam.width, rows = a.row_end - a.row_begin;
+  if (a.flags & RM_FLAG_TILE8X8) {
+    const int tw = (W + 7) >> 3, th = (rows + 7) >> 3;
+    int64_t wave_global = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t per_cam = (int64_t)tw * th;
+    cam = (int)(wave_global / per_cam);
+    int64_t t = wave_global - (int64_t)cam * per_cam;
+    int ty = (int)(t / tw), tx = (int)(t - (int64_t)ty * tw);
+    row = ty * 8 + (lane >> 3);
+    col = tx * 8 + (lane & 7);
+    return cam < a.cam.num_cameras && row < rows && col < W;
+  }
+  int64_t li = tile * blockDim.x + threadIdx.x;
+  int64_t per_cam = (int64_t)rows * W;
+  cam = (int)(li / per_cam);
+  int64_t r = li - (int64_t)cam * per_cam;
+  row = (int)(r / W);
+  col = (int)(r - (int64_t)row * W);
+  return cam < a.cam.num_cameras;
+}
+
+RM_DEV int64_t render_tiles(const RenderArgs& a, int block) {
+  const int W = a.cam.width, rows = a.row_end - a.row_begin;
+  if (a.flags & RM_FLAG_TILE8X8) {
+    int64_t waves = (int64_t)a.cam.num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3);
+    int wpb = block >> 6;
+    return (waves + wpb - 1) / wpb;
+  }
+  int64_t R = (int64_t)a.cam.num_cameras * rows * W;
+  return (R + block - 1) / block;
+}
+
+RM_DEV Pose load_pose(const float* orientation, const float* translation, int cam) {
+  Pose ps;
+  ps.w = orientation[4 * cam];
+  ps.qv = mk3(orientation[4 * cam + 1], orientation[4 * cam + 2], orientation[4 * cam + 3]);
+  ps.t = mk3(translation[3 * cam], translation[3 * cam + 1], translation[3 * cam + 2]);
+  return ps;
+}
+
+// angle_colouring / domain_colouring (shader.py:92-118)
+RM_DEV V3 domain_colour(float re, float im, const float* cmap, int size, int degree) {
+  const float tau = 6.283185307179586f;
+  float x = (((atan2f(im, re) / tau) + 0.5f) * (float)degree) * (float)size;
+  long long idx = (long long)floorf(x);
+  long long m = idx % size;
+  if (m < 0) m += size;
+  float bright = __fsqrt_rn(re * re + im * im);
+  if (!(x == x)) { m = 0; bright = x; }  // NaN normal: propagate NaN instead of indexing with it
+  return mk3(bright * cmap[3 * m], bright * cmap[3 * m + 1], bright * cmap[3 * m + 2]);
+}
+
+struct ShadeIn {
+  V3 o, v, p, n;      // pixel (ray origin) position, ray direction, surface point, surface normal
+  float lap, dist;
+  float qw; V3 qv;    // camera orientation
+  V3 col2;            // pixel_frames[..., 2]
+};
+
+// One pixel of Shader.forward (shader.py:190-263).  Modes 1, 2, 5 return the
+// un-normalised value; rm_shade_finish applies the global min/max.
+RM_DEV V3 shade_pixel(int mode, const ShadeIn& s, const float* cmap, int cmap_size, int degree) {
+  switch (mode) {
+    case RM_MODE_LAMBERTIAN: {  // shader.py:16-20
+      float c = t_clamp(-dot_seq(s.v, s.n), 0.0f, 1.0f);
+      return mk3(c, c, c);
+    }
+    case RM_MODE_DISTANCE: {    // shader.py:27-33
+      float l = logf(t_clamp(norm3(s.o - s.p), 1e-2f, __builtin_inff()));
+      return mk3(l, l, l);
+    }
+    case RM_MODE_PROXIMITY: {   // shader.py:45-50
+      float l = logf(t_clamp(s.dist, 1e-2f, __builtin_inff()));
+      return mk3(l, l, l);
+    }
+    case RM_MODE_VIGNETTE: {    // shader.py:62-66
+      float d = dot_seq(s.v, s.col2);
+      float c = (d * d) * d;
+      return mk3(c, c, c);
+    }
+    case RM_MODE_NORMAL:        // shader.py:73-74
+      return mk3(t_clamp(fabsf(s.n.x), 0.0f, 1.0f), t_clamp(fabsf(s.n.y), 0.0f, 1.0f),
+                 t_clamp(fabsf(s.n.z), 0.0f, 1.0f));
+    case RM_MODE_LAPLACIAN:     // shader.py:81-89
+      return mk3(s.lap, s.lap, s.lap);
+    case RM_MODE_TANGENT: {     // shader.py:125-150
+      float c = dot_seq(s.n, s.v);
+      V3 tg = mk3((c * s.v.x) * -1.0f + s.n.x, (c * s.v.y) * -1.0f + s.n.y, (c * s.v.z) * -1.0f + s.n.z);
+      V3 pr = qrot(tg, s.qw, neg(s.qv));
+      return domain_colour(pr.x, pr.y, cmap, cmap_size, degree);
+    }
+    default: {                  // RM_MODE_SPIN, shader.py:157-171: (0,n) * conj(q)
+      float q0 = s.qw, q1 = -s.qv.x, q2 = -s.qv.y, q3 = -s.qv.z;
+      float p0 = 0.0f, p1 = s.n.x, p2 = s.n.y, p3 = s.n.z;
+      float r0 = p0 * q0 - ((p1 * q1 + p2 * q2) + p3 * q3);
+      float r1 = ((p0 * q1 + p1 * q0) + p2 * q3) - p3 * q2;
+      float r2 = ((p0 * q2 + p2 * q0) + p3 * q1) - p1 * q3;
+      float r3 = ((p0 * q3 + p1 * q2) + p3 * q0) - p2 * q1;
+      float re = r0 * r0 - ((r1 * r1 + r2 * r2) + r3 * r3);
+      float im = (norm3(mk3(r1, r2, r3)) * r0) * 2.0f;
+      return domain_colour(im, re, cmap, cmap_size, degree);   // (imag, real) swapped as in the reference
+    }
+  }
+}
+
+// fold a wave's running min/max (+NaN flag) into the global minmax words
+RM_DEV void fold_minmax(uint32_t* minmax, float lo, float hi, bool saw_nan) {
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  unsigned long long nanmask = __ballot(saw_nan);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&minmax[0], f2ord(lo));
+    atomicMax(&minmax[1], f2ord(hi));
+    if (nanmask) atomicOr(&minmax[2], 1u);
+  }
+}
+
+// Standalone Shader.forward over tensors (any of the inputs a mode does not read may be null).
+struct ShadeArgs {
+  const float *px, *orientation, *frames, *dirs, *coords, *normals, *lap, *dist;
+  float* image;
+  uint32_t* minmax;
+  const float* cmap;
+  int32_t cmap_size, mode, degree;
+  int64_t n, per_camera;
+};
+
+__global__ void k_shade_fwd(ShadeArgs a) {
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  bool saw_nan = false;
+  const V3 z = mk3(0.0f, 0.0f, 0.0f);
+  int64_t ntiles = (a.n + blockDim.x - 1) / blockDim.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t i = tile * blockDim.x + threadIdx.x;
+    if (i >= a.n) continue;
+    int cam = (int)(i / a.per_camera);
+    ShadeIn s;
+    s.o = a.px ? load3(a.px, i) : z;
+    s.v = a.dirs ? load3(a.dirs, i) : z;
+    s.p = a.coords ? load3(a.coords, i) : z;
+    s.n = a.normals ? load3(a.normals, i) : z;
+    s.lap = a.lap ? a.lap[i] : 0.0f;
+    s.dist = a.dist ? a.dist[i] : 0.0f;
+    s.qw = a.orientation ? a.orientation[4 * cam] : 1.0f;
+    s.qv = a.orientation ? mk3(a.orientation[4 * cam + 1], a.orientation[4 * cam + 2], a.orientation[4 * cam + 3]) : z;
+    s.col2 = a.frames ? mk3(a.frames[9 * cam + 2], a.frames[9 * cam + 5], a.frames[9 * cam + 8]) : z;
+    V3 out = shade_pixel(a.mode, s, a.cmap, a.cmap_size, a.degree);
+    store3(a.image, i, out);
+    if (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY) {
+      saw_nan |= (out.x != out.x);
+      lo = fminf(lo, out.x); hi = fmaxf(hi, out.x);
+    } else if (a.mode == RM_MODE_LAPLACIAN) {
+      saw_nan |= (out.x != out.x);
+      hi = fmaxf(hi, fabsf(out.x));
+    }
+  }
+  if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
+    fold_minmax(a.minmax, lo, hi, saw_nan);
+}
+
+template <class Cfg>
+__global__ void k_render_fwd(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  Tetra T = load_tetra(a.tetra);
+  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
+  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
+  const bool early = a.flags & RM_FLAG_EARLY_OUT;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  bool saw_nan = false;
+  int64_t ntiles = render_tiles(a, blockDim.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int cam, row, col;
+    bool live = ray_of_lane(a, tile, cam, row, col);
+    if (!live) { cam = 0; row = 0; col = 0; }
+    int64_t li = ((int64_t)cam * rows + row) * W + col;                  // index in the band outputs
+    int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;     // index in the camera buffers
+    Pose ps = load_pose(a.orientation, a.translation, cam);
+    // PinholeCamera.forward (ray_marching.py:58-62)
+    V3 o = qrot(load3(a.cam.ray_positions, gi), ps.w, ps.qv) + ps.t;
+    V3 v = qrot(load3(a.cam.ray_directions, gi), ps.w, ps.qv);
+    int nexec;
+    V3 p = march(scene, o, v, a.steps, early, a.traj, R, li, live, nexec);
+    float dist = scene.eval(p);                                          // control.py:244
+    V3 n = mk3(0.0f, 0.0f, 0.0f);
+    float lap = 0.0f;
+    const int mode = a.mode;
+    if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap);
+    ShadeIn si;
+    si.o = o; si.v = v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
+    si.qw = ps.w; si.qv = ps.qv;
+    {   // third column of the camera rotation (QuaternionToSO3, quaternion.py:114-124)
+      float w = ps.w, x = ps.qv.x, y = ps.qv.y, z = ps.qv.z;
+      si.col2 = mk3(2.0f * (w * y + x * z), 2.0f * (y * z - w * x), ((w * w - x * x) - y * y) + z * z);
+    }
+    V3 out = shade_pixel(mode, si, a.cmap, a.cmap_size, a.degree);
+    if (live) {
+      store3(a.image, li, out);
+      if (a.p_final) store3(a.p_final, li, p);
+      if (a.nexec) a.nexec[li] = nexec;
+      if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
+        saw_nan |= (out.x != out.x);
+        lo = fminf(lo, out.x); hi = fmaxf(hi, out.x);
+      } else if (mode == RM_MODE_LAPLACIAN) {
+        saw_nan |= (lap != lap);
+        hi = fmaxf(hi, fabsf(lap));
+      }
+    }
+  }
+  if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
+    fold_minmax(a.minmax, lo, hi, saw_nan);
+}
+
+// second pass for the globally normalised shaders
+__global__ void k_shade_finish(float* __restrict__ image, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
+  float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
+  if (minmax[2]) { lo = __builtin_nanf(""); hi = lo; }
+  const float gamma = (float)(1.0 / 2.33);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float x = image[3 * i];
+    float y;
+    if (mode == RM_MODE_LAPLACIAN) {   // shader.py:83-88
+      y = powf(t_clamp((((x / hi) * -1.0f) + 1.0f) / 2.0f, 0.0f, 1.0f), gamma);
+    } else {                           // shader.py:34-38 / 51-55
+      y = powf((x - lo) / (hi - lo), gamma);
+    }
+    image[3 * i] = y; image[3 * i + 1] = y; image[3 * i + 2] = y;
+  }
+}
+
+__global__ void k_minmax_init(uint32_t* mm) {
+  mm[0] = f2ord(__builtin_inff()); mm[1] = f2ord(-__builtin_inff()); mm[2] = 0u; mm[3] = 0u;
+}
+__global__ void k_minmax_decode(const uint32_t* mm, float* lohi) {
+  float nanv = __builtin_nanf("");
+  lohi[0] = mm[2] ? nanv : ord2f(mm[0]);
+  lohi[1] = mm[2] ? nanv : ord2f(mm[1]);
+}
+__global__ void k_minmax_encode(const float* lohi, uint32_t* mm) {
+  bool isn = (lohi[0] != lohi[0]) || (lohi[1] != lohi[1]);
+  mm[0] = f2ord(lohi[0]); mm[1] = f2ord(lohi[1]); mm[2] = isn ? 1u : 0u; mm[3] = 0u;
+}
+
+// standalone PinholeCamera.forward
+__global__ void k_camera_fwd(RmCamera cam, const float* __restrict__ orientation, const float* __restrict__ translation,
+                             float* __restrict__ out_pos, float* __restrict__ out_dirs, float* __restrict__ frames) {
+  int64_t per_cam = (int64_t)cam.height * cam.width;
+  int64_t n = per_cam * cam.num_cameras;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i / per_cam);
+    Pose ps = load_pose(orientation, translation, c);
+    store3(out_pos, i, qrot(load3(cam.ray_positions, i), ps.w, ps.qv) + ps.t);
+    store3(out_dirs, i, qrot(load3(cam.ray_directions, i), ps.w, ps.qv));
+  }
+  // QuaternionToSO3 (quaternion.py:114-124)
+  if (frames && blockIdx.x == 0 && (int)threadIdx.x < cam.num_cameras) {
+    int c = threadIdx.x;
+    float w = orientation[4 * c], x = orientation[4 * c + 1], y = orientation[4 * c + 2], z = orientation[4 * c + 3];
+    float ww = w * w, wx = w * x, wy = w * y, wz = w * z, xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+    float* f = frames + 9 * c;
+    f[0] = ((ww + xx) - yy) - zz; f[1] = 2.0f * (xy - wz); f[2] = 2.0f * (wy + xz);
+    f[3] = 2.0f * (xy + wz); f[4] = ((ww - xx) + yy) - zz; f[5] = 2.0f * (yz - wx);
+    f[6] = 2.0f * (xz - wy); f[7] = 2.0f * (wx + yz); f[8] = ((ww - xx) - yy) + zz;
+  }
+}
+
+// VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
+template <class Cfg>
+__global__ void k_render_bwd(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  const int n_acc = a.scene.n_params + a.scene.n_derived;
+  zero_accumulators(scene, n_acc);
+  Tetra T = load_tetra(a.tetra);
+  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
+  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
+  int64_t ntiles = render_tiles(a, blockDim.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int cam, row, col;
+    bool live = ray_of_lane(a, tile, cam, row, col);
+    if (!live) { cam = 0; row = 0; col = 0; }
+    int64_t li = ((int64_t)cam * rows + row) * W + col;
+    int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;
+    Pose ps = load_pose(a.orientation, a.translation, cam);
+    V3 v = qrot(load3(a.cam.ray_directions, gi), ps.w, ps.qv);
+    V3 p = load3(a.p_final, li);
+    V3 gi3 = live ? load3(a.grad_image, li) : mk3(0.0f, 0.0f, 0.0f);
+    // recompute the normal for the shader VJP
+    float c0 = 0.0f;
+    V3 n; float lap;
+    normals_forward(scene, T, p, c0, n, lap);
+    V3 gn;
+    if (a.mode == RM_MODE_LAMBERTIAN) {
+      float c = -dot_seq(v, n);
+      float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
+      gn = mk3(-g * v.x, -g * v.y, -g * v.z);
+    } else {  // RM_MODE_NORMAL
+      gn = mk3((fabsf(n.x) <= 1.0f) ? gi3.x * sgn0(n.x) : 0.0f,
+               (fabsf(n.y) <= 1.0f) ? gi3.y * sgn0(n.y) : 0.0f,
+               (fabsf(n.z) <= 1.0f) ? gi3.z * sgn0(n.z) : 0.0f);
+    }
+    V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
+    int ne = a.nexec ? a.nexec[li] : a.steps;
+    march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, nullptr);
+  }
+  flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
+}
+
+// Sum the per-block partials in block order (deterministic), then push the
+// gradients of the derived capsule constants back onto start/end
+// (AB = end - start, ABs = AB / |AB|^2; primitives.py:52-54).
+__global__ void k_reduce_partials(RmScene sc, const float* __restrict__ partials, int nblocks,
+                                  float* __restrict__ grad_params) {
+  extern __shared__ float s_acc[];
+  const int n_acc = sc.n_params + sc.n_derived;
+  for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
+    float sum = 0.0f;
+    for (int b = 0; b < nblocks; ++b) sum += partials[(int64_t)b * n_acc + i];
+    s_acc[i] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int4* prog = reinterpret_cast<const int4*>(sc.program);
+    for (int pc = 0; pc < sc.n_instr; ++pc) {
+      int4 w = prog[pc];
+      if (w.x != RM_OP_LINE) continue;
+      const float* a = sc.params + w.y;
+      float ab[3] = {a[3] - a[0], a[4] - a[1], a[5] - a[2]};
+      float len2 = (ab[0] * ab[0] + ab[1] * ab[1]) + ab[2] * ab[2];
+      const float* gab = s_acc + w.z;
+      const float* gabs = s_acc + w.z + 3;
+      // ABs = AB / len2 : g_AB += gABs/len2 ; g_len2 = -sum(gABs * AB)/len2^2 ; len2 = sum AB^2
+      float glen2 = -((gabs[0] * ab[0] + gabs[1] * ab[1]) + gabs[2] * ab[2]) / (len2 * len2);
+      for (int k = 0; k < 3; ++k) {
+        float g = gab[k] + gabs[k] / len2 + 2.0f * ab[k] * glen2;
+        s_acc[w.y + 3 + k] += g;   // end
+        s_acc[w.y + k] -= g;       // start
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < sc.n_params; i += blockDim.x) grad_params[i] = s_acc[i];
+}
+
+}  // namespace rm

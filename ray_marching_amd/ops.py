@@ -1,0 +1,292 @@
+"""autograd.Function wrappers over the C ABI (librm_hip.so).
+
+Each Function hands raw device pointers and the current HIP stream to one entry
+point of include/rm_abi.h.  PyTorch only supplies device memory, the stream and
+the autograd tape; all arithmetic happens in the HIP kernels.  Inputs must live
+on a HIP device: there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+from .compiler import CompiledScene
+
+_lib = _abi.lib
+
+
+def _require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"ray_marching_amd: {what} is on {t.device}; the HIP kernels need a ROCm device tensor "
+            "(no CPU fallback exists by design)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _partials(cs: CompiledScene, params, device):
+    s, keep = cs.scene_struct(params, device)
+    n = _lib.rm_grad_partials_floats(s, 0)
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
+def default_flags(early_out: bool = True, tile8x8: bool = False) -> int:
+    return (_abi.FLAG_EARLY_OUT if early_out else 0) | (_abi.FLAG_TILE8X8 if tile8x8 else 0)
+
+
+# --------------------------------------------------------------------------
+# scene(query) -> distance
+# --------------------------------------------------------------------------
+class SDFEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, points, cs: CompiledScene):
+        _require_device(points, "query_positions")
+        dev = points.device
+        pts = _f32c(points).reshape(-1, 3)
+        prm = _f32c(params)
+        n = pts.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            _abi.check(_lib.rm_sdf_forward(s, _abi.ptr(pts), _abi.ptr(out), n, _abi.current_stream(dev)),
+                       "rm_sdf_forward")
+        ctx.cs = cs
+        ctx.in_dtype = points.dtype
+        ctx.save_for_backward(prm, pts)
+        return out.view(*points.shape[:-1], 1).to(points.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        prm, pts = ctx.saved_tensors
+        cs, dev = ctx.cs, pts.device
+        n = pts.shape[0]
+        if n == 0:
+            return torch.zeros_like(prm), torch.zeros(*grad_out.shape[:-1], 3, dtype=ctx.in_dtype, device=dev), None
+        g = _f32c(grad_out).reshape(-1)
+        gpts = torch.empty_like(pts) if ctx.needs_input_grad[1] else None
+        gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            part = _partials(cs, prm, dev)
+            _abi.check(_lib.rm_sdf_backward(s, _abi.ptr(pts), _abi.ptr(g), _abi.ptr(gpts), _abi.ptr(gprm),
+                                            _abi.ptr(part), n, _abi.current_stream(dev)), "rm_sdf_backward")
+        gp = gpts.view(*grad_out.shape[:-1], 3).to(ctx.in_dtype) if gpts is not None else None
+        return gprm[: prm.numel()], gp, None
+
+
+# --------------------------------------------------------------------------
+# marcher
+# --------------------------------------------------------------------------
+class March(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, pos, dirs, cs: CompiledScene, steps: int, flags: int):
+        _require_device(pos, "ray_positions")
+        _require_device(dirs, "ray_directions")
+        dev = pos.device
+        shape = torch.broadcast_shapes(pos.shape, dirs.shape)
+        p = _f32c(pos.expand(shape)).reshape(-1, 3)
+        v = _f32c(dirs.expand(shape)).reshape(-1, 3)
+        prm = _f32c(params)
+        n = p.shape[0]
+        need_grad = any(ctx.needs_input_grad[:3])
+        out = torch.empty_like(p)
+        traj = torch.empty((steps, n, 3), dtype=torch.float32, device=dev) if (need_grad and steps > 0) else None
+        nexec = torch.empty(n, dtype=torch.int32, device=dev) if need_grad else None
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            _abi.check(_lib.rm_march_forward(s, _abi.ptr(p), _abi.ptr(v), _abi.ptr(out), _abi.ptr(traj),
+                                             _abi.ptr(nexec), n, steps, flags, _abi.current_stream(dev)),
+                       "rm_march_forward")
+        ctx.cs, ctx.steps, ctx.shape, ctx.in_dtype = cs, steps, shape, pos.dtype
+        ctx.pos_shape, ctx.dirs_shape = pos.shape, dirs.shape
+        if need_grad:
+            ctx.save_for_backward(prm, v, traj, nexec)
+        return out.view(shape).to(pos.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        prm, v, traj, nexec = ctx.saved_tensors
+        cs, dev, steps = ctx.cs, v.device, ctx.steps
+        n = v.shape[0]
+        g = _f32c(grad_out.expand(ctx.shape)).reshape(-1, 3)
+        if steps == 0 or n == 0:
+            return torch.zeros_like(prm), grad_out, torch.zeros_like(grad_out), None, None, None
+        gpos = torch.empty_like(v)
+        gdirs = torch.empty_like(v) if ctx.needs_input_grad[2] else None
+        gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            part = _partials(cs, prm, dev)
+            _abi.check(_lib.rm_march_backward(s, _abi.ptr(v), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(g),
+                                              _abi.ptr(gpos), _abi.ptr(gdirs), _abi.ptr(gprm), _abi.ptr(part),
+                                              n, steps, _abi.current_stream(dev)), "rm_march_backward")
+
+        def fit(t, shape):
+            t = t.view(ctx.shape).to(ctx.in_dtype)
+            return t.sum_to_size(shape) if tuple(shape) != tuple(ctx.shape) else t
+
+        return (gprm[: prm.numel()], fit(gpos, ctx.pos_shape),
+                fit(gdirs, ctx.dirs_shape) if gdirs is not None else None, None, None, None)
+
+
+# --------------------------------------------------------------------------
+# normals / laplacian
+# --------------------------------------------------------------------------
+def make_tetra(offsets: torch.Tensor, inverse: torch.Tensor, eps: float) -> _abi.RmTetra:
+    t = _abi.RmTetra()
+    o = offsets.detach().float().cpu().reshape(-1).tolist()
+    m = inverse.detach().float().cpu().reshape(-1).tolist()
+    for i in range(12):
+        t.offsets[i] = o[i]
+    for i in range(9):
+        t.inverse[i] = m[i]
+    t.lap_scale = float(torch.tensor(6 / eps ** 2, dtype=torch.float32))
+    return t
+
+
+class Normals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, coords, cs: CompiledScene, tetra):
+        _require_device(coords, "surface_coords")
+        dev = coords.device
+        pts = _f32c(coords).reshape(-1, 3)
+        prm = _f32c(params)
+        n = pts.shape[0]
+        nrm = torch.empty_like(pts)
+        lap = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            _abi.check(_lib.rm_normals_forward(s, tetra, _abi.ptr(pts), _abi.ptr(nrm), _abi.ptr(lap), n,
+                                               _abi.current_stream(dev)), "rm_normals_forward")
+        ctx.cs, ctx.tetra, ctx.in_dtype = cs, tetra, coords.dtype
+        ctx.save_for_backward(prm, pts)
+        return nrm.view(coords.shape).to(coords.dtype), lap.view(*coords.shape[:-1], 1).to(coords.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_n, grad_lap):
+        prm, pts = ctx.saved_tensors
+        cs, dev = ctx.cs, pts.device
+        n = pts.shape[0]
+        gn = _f32c(grad_n).reshape(-1, 3) if grad_n is not None else None
+        gl = _f32c(grad_lap).reshape(-1) if grad_lap is not None else None
+        gpts = torch.empty_like(pts) if ctx.needs_input_grad[1] else None
+        gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            part = _partials(cs, prm, dev)
+            _abi.check(_lib.rm_normals_backward(s, ctx.tetra, _abi.ptr(pts), _abi.ptr(gn), _abi.ptr(gl),
+                                                _abi.ptr(gpts), _abi.ptr(gprm), _abi.ptr(part), n,
+                                                _abi.current_stream(dev)), "rm_normals_backward")
+        shape = grad_n.shape if grad_n is not None else (*grad_lap.shape[:-1], 3)
+        gp = gpts.view(shape).to(ctx.in_dtype) if gpts is not None else None
+        return gprm[: prm.numel()], gp, None, None
+
+
+# --------------------------------------------------------------------------
+# camera
+# --------------------------------------------------------------------------
+def camera_struct(ray_positions, ray_directions):
+    n, h, w, _ = ray_positions.shape
+    return _abi.RmCamera(ray_positions=ray_positions.data_ptr(), ray_directions=ray_directions.data_ptr(),
+                         num_cameras=n, height=h, width=w)
+
+
+def camera_forward(ray_positions, ray_directions, orientation, translation):
+    _require_device(ray_positions, "camera buffers")
+    _require_device(orientation, "orientation")
+    dev = ray_positions.device
+    rp, rd = _f32c(ray_positions), _f32c(ray_directions)
+    q, t = _f32c(orientation), _f32c(translation)
+    n = rp.shape[0]
+    if q.shape != (n, 4) or t.shape != (n, 3):
+        raise ValueError(f"camera pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
+    pos, dirs = torch.empty_like(rp), torch.empty_like(rd)
+    frames = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        cam = camera_struct(rp, rd)
+        _abi.check(_lib.rm_camera_forward(cam, _abi.ptr(q), _abi.ptr(t), _abi.ptr(pos), _abi.ptr(dirs),
+                                          _abi.ptr(frames), _abi.current_stream(dev)), "rm_camera_forward")
+    dt = ray_positions.dtype
+    return pos.to(dt), frames.to(dt), dirs.to(dt)
+
+
+# --------------------------------------------------------------------------
+# fused frame
+# --------------------------------------------------------------------------
+_GLOBAL_MODES = (1, 2, 5)
+
+
+class Render(torch.autograd.Function):
+    """RenderLoop.forward as one kernel (+ the normalisation pass of modes 1, 2, 5).
+
+    ``allreduce_minmax``: optional callable(lohi_tensor[2]) applied between the two passes
+    (row-tiled multi-GPU rendering all-reduces the global min/max there)."""
+
+    @staticmethod
+    def forward(ctx, params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions,
+                tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax):
+        _require_device(ray_positions, "camera buffers")
+        _require_device(orientation, "orientations")
+        dev = ray_positions.device
+        prm = _f32c(params)
+        q, t = _f32c(orientation), _f32c(translation)
+        n, h, w, _ = ray_positions.shape
+        if q.shape != (n, 4) or t.shape != (n, 3):
+            raise ValueError(f"pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
+        r0, r1 = rows if rows is not None else (0, h)
+        nrows = r1 - r0
+        R = n * nrows * w
+        need_grad = ctx.needs_input_grad[0]
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("gradients w.r.t. the camera pose are not implemented in the fused frame "
+                                      "(SURVEY 8 f2); detach orientations/translations")
+        if need_grad and mode not in (0, 4):
+            raise NotImplementedError(f"fused backward exists for shader modes 0 (lambertian) and 4 (normal), not {mode}")
+        image = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
+        p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if need_grad else None
+        traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (need_grad and steps > 0) else None
+        nexec = torch.empty(R, dtype=torch.int32, device=dev) if need_grad else None
+        minmax = torch.empty(4, dtype=torch.int32, device=dev) if mode in _GLOBAL_MODES else None
+        with torch.cuda.device(dev):
+            stream = _abi.current_stream(dev)
+            s, keep = cs.scene_struct(prm, dev)
+            cam = camera_struct(ray_positions, ray_directions)
+            if minmax is not None:
+                _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
+            _abi.check(_lib.rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
+                                              _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
+                                              _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
+                                              mode, degree, steps, r0, r1, flags, stream), "rm_render_forward")
+            if minmax is not None:
+                if allreduce_minmax is not None:
+                    lohi = torch.empty(2, dtype=torch.float32, device=dev)
+                    _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
+                    allreduce_minmax(lohi)
+                    _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
+                _abi.check(_lib.rm_shade_finish(_abi.ptr(image), n * nrows * w, _abi.ptr(minmax), mode, stream),
+                           "rm_shade_finish")
+        if need_grad:
+            ctx.save_for_backward(prm, q, t, ray_positions, ray_directions, p_final, traj, nexec)
+            ctx.cs, ctx.tetra, ctx.mode, ctx.steps, ctx.rows = cs, tetra, mode, steps, (r0, r1)
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        prm, q, t, rp, rd, p_final, traj, nexec = ctx.saved_tensors
+        cs, dev = ctx.cs, rp.device
+        g = _f32c(grad_image)
+        gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s, keep = cs.scene_struct(prm, dev)
+            cam = camera_struct(rp, rd)
+            part = _partials(cs, prm, dev)
+            _abi.check(_lib.rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
+                                               _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
+                                               _abi.ptr(part), ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1],
+                                               _abi.current_stream(dev)), "rm_render_backward")
+        return (gprm[: prm.numel()],) + (None,) * 13

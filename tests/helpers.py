@@ -1,0 +1,72 @@
+"""Shared test helpers: oracle spec <-> product module conversion, fixtures, tolerances."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import sdf_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PX = 3.45e-6
+EPS = 5e-2
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def spec_to_module(spec):
+    """Oracle scene spec -> ray_marching_amd nn.Module tree (parameter values copied)."""
+    from ray_marching_amd.scene import primitives as P, transformations as T
+    kind, prm = spec[0], spec[1]
+
+    def f(x):
+        return x.detach().tolist()
+
+    if kind == "sphere":
+        return P.SDFSphere(f(prm["radius"]))
+    if kind == "box":
+        return P.SDFBox(tuple(f(prm["halfsides"])))
+    if kind == "plane":
+        return P.SDFPlane()
+    if kind == "line":
+        return P.SDFLine(tuple(f(prm["start"])), tuple(f(prm["end"])), f(prm["radius"]))
+    if kind == "disk":
+        return P.SDFDisk(f(prm["radius"]))
+    if kind == "torus":
+        return P.SDFTorus(f(prm["radius1"]), f(prm["radius2"]))
+    if kind == "affine":
+        return T.SDFAffineTransformation(spec_to_module(spec[2]), orientation=f(prm["orientation"]),
+                                         translation=f(prm["translation"]))
+    if kind == "smooth_union":
+        return T.SDFSmoothUnion([spec_to_module(c) for c in spec[2]], f(prm["blend_k"]))
+    if kind == "union":
+        return T.SDFUnion([spec_to_module(c) for c in spec[2]])
+    if kind == "rounding":
+        return T.SDFRounding(spec_to_module(spec[2]), f(prm["rounding"]))
+    if kind == "onion":
+        return T.SDFOnion(spec_to_module(spec[2]), f(prm["radius"]))
+    raise ValueError(kind)
+
+
+def node_specs():
+    from oracle.gen_golden import node_specs as ns
+    return ns()
+
+
+def make_loop(module, h, w, n=1, device="cuda", **kw):
+    from ray_marching_amd.control import RenderLoop
+    return RenderLoop(module, num_cameras=n, px_width=w, px_height=h, focal_length=PX * h,
+                      sensor_width=PX * w, sensor_height=PX * h, normals_eps=EPS, **kw).to(device)
+
+
+def report(name, got, want):
+    """max abs error, fraction of elements beyond 1e-5 (NaN positions must agree)."""
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    nan_g, nan_w = torch.isnan(got), torch.isnan(want)
+    assert torch.equal(nan_g, nan_w), f"{name}: NaN pattern differs ({nan_g.sum()} vs {nan_w.sum()})"
+    err = (torch.nan_to_num(got) - torch.nan_to_num(want)).abs()
+    err = torch.where(torch.isinf(got) & (got == want), torch.zeros_like(err), err)
+    return float(err.max()) if err.numel() else 0.0, float((err > 1e-5).double().mean()) if err.numel() else 0.0
