@@ -51,14 +51,33 @@ def parse():
     return ap.parse_args()
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a 16-CPU box share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("RM_CPU_THREADS", "16"))))
+
+
 def cpu_baseline():
     """The oracle (eager PyTorch CPU restatement of the reference, bit-exact with it in the
     build container) on this box's host cores, on a bounded sample of the same workload:
     every 2nd pixel row and column of the 1920x1080 grid (960x540 rays, same ray
     distribution), 128 steps, normal + Lambertian frames; best of 2 after one warm-up."""
     from oracle import sdf_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads ...")
     bufs = O.camera_buffers(1, W, H_TILE, PX * H_TILE, PX * W, PX * H_TILE)
     sub = tuple(b[:, ::2, ::2].contiguous() for b in bufs)
     q = torch.tensor([[1.0, 0.0, 0.0, 0.0]])
@@ -72,6 +91,7 @@ def cpu_baseline():
             for m in MODES:
                 O.render(spec, sub, q, t, m, 1, STEPS_MARCH, EPS)
             dt = time.perf_counter() - t0
+            log(f"cpu_baseline: pass {it} {dt:.2f} s")
             if it > 0:
                 best = min(best, dt)
     return {"value": rays / best / 1e6, "unit": "Mrays/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -174,6 +194,7 @@ def main():
             handles.append(img)
         return handles
 
+    log(f"rank {rank}/{world}: warm-up {args.warmup}, timing {args.steps} steps")
     with torch.no_grad():
         for i in range(args.warmup):
             one_step(i, False)
@@ -199,6 +220,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    log(f"timed region {elapsed:.3f} s")
     per_launch_ms = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(len(kernel_ms), 1)
     total_rays = rays_per_frame * len(MODES) * args.steps * world
     value = total_rays / elapsed / 1e6
@@ -235,7 +257,9 @@ def main():
                                   "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer"}},
         }
         if not args.skip_backward:
+            log("backward probe (config 4 shape) ...")
             out["fwd_bwd"] = backward_probe(dev)
+            log(f"backward probe: {out['fwd_bwd']}")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -43,9 +43,12 @@ RM_DEV float dot_seq(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RM_DEV V3 cross(V3 a, V3 b) {
   return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// Correctly rounded sqrt (ATen CPU = IEEE sqrt).  NOTE: hipcc lowers __fsqrt_rn to the bare
+// 1-ulp v_sqrt_f32; sqrtf() is the one that adds the +-1 ulp correction (measured).
+RM_DEV float rm_sqrt(float x) { return __builtin_sqrtf(x); }
 // ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
-RM_DEV float norm3(V3 a) { return __fsqrt_rn(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
-RM_DEV float norm2(float a, float b) { return __fsqrt_rn(__builtin_fmaf(b, b, a * a)); }
+RM_DEV float norm3(V3 a) { return rm_sqrt(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
+RM_DEV float norm2(float a, float b) { return rm_sqrt(__builtin_fmaf(b, b, a * a)); }
 // quaternion.py:55-72: V + w*t + qv x t, t = 2*(qv x V); summed as (y + w*t) + V.
 RM_DEV V3 qrot(V3 v, float w, V3 qv) {
   V3 t = 2.0f * cross(qv, v);

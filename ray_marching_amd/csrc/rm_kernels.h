@@ -421,7 +421,7 @@ RM_DEV V3 domain_colour(float re, float im, const float* cmap, int size, int deg
   long long idx = (long long)floorf(x);
   long long m = idx % size;
   if (m < 0) m += size;
-  float bright = __fsqrt_rn(re * re + im * im);
+  float bright = rm_sqrt(re * re + im * im);
   if (!(x == x)) { m = 0; bright = x; }  // NaN normal: propagate NaN instead of indexing with it
   return mk3(bright * cmap[3 * m], bright * cmap[3 * m + 1], bright * cmap[3 * m + 2]);
 }
