@@ -77,23 +77,27 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  ray_marching_amd has no CPU or PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    return bind(C.CDLL(LIB_PATH))
+
+
+def bind(lib):
+    """Attach the ABI signatures to a loaded library (generic or per-scene specialised)."""
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = ABI symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
     got = lib.rm_abi_version()
     if got != ABI_VERSION:
-        raise ImportError(f"librm_hip.so ABI version {got}, expected {ABI_VERSION}: rebuild")
+        raise ImportError(f"{lib._name}: ABI version {got}, expected {ABI_VERSION}: rebuild")
     return lib
 
 
 lib = _load()
 
 
-def check(code: int, what: str):
+def check(code: int, what: str, from_lib=None):
     if code != 0:
-        raise RmError(f"{what} failed ({code}): {lib.rm_last_error().decode()}")
+        raise RmError(f"{what} failed ({code}): {(from_lib or lib).rm_last_error().decode()}")
 
 
 def ptr(t):

@@ -38,6 +38,22 @@ class CompiledScene:
     signature: tuple                    # topology key (ops + offsets), parameters excluded
     _device_programs: dict = field(default_factory=dict)
     _packed: dict = field(default_factory=dict)
+    _lib: object = None
+
+    def lib(self, backward: bool = False):
+        """Kernel library for this scene: the per-scene specialised build when one is available
+        (ray_marching_amd/specialize.py), else the generic interpreter library.  Backward of
+        scenes with many parameters always uses the generic library (accumulators in LDS)."""
+        from . import specialize
+        if backward and not specialize.static_backward(self):
+            return _abi.lib
+        if self._lib is None:
+            self._lib = specialize.load(self) or _abi.lib
+        return self._lib
+
+    @property
+    def specialised(self) -> bool:
+        return self.lib() is not _abi.lib
 
     @property
     def n_instr(self):

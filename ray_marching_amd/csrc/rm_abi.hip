@@ -1,7 +1,15 @@
 // rm_abi.hip -- C ABI (include/rm_abi.h) over the generic interpreter kernels.
 // Built for gfx950 only:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC rm_abi.hip -o librm_hip.so
+//
+// Second build mode: -DRM_STATIC_CODE='"code_<hash>.h"' bakes one scene program in at compile
+// time (rm::StaticCfg): same entry points, same handlers, but the interpreter loop, the LDS
+// stack/tape and the scalar branches are gone (ray_marching_amd/specialize.py drives this).
 #include "rm_kernels.h"
+
+#ifdef RM_STATIC_CODE
+#include RM_STATIC_CODE
+#endif
 
 #include <cstdarg>
 #include <cstdio>
@@ -24,13 +32,15 @@ constexpr int kMaxBlocksBwd = 1024;     // also the partials row count
 constexpr size_t kLdsDefault = 64 * 1024;
 constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
 
+int check_static(const RmScene* sc);
+
 int check_scene(const RmScene* sc) {
   if (!sc || !sc->program || (!sc->params && sc->n_params > 0))
     return fail(RM_E_BADARG, "scene: null program/params");
   if (sc->n_instr <= 0 || sc->n_instr > 4096 || sc->n_params < 0 || sc->n_derived < 0 ||
       sc->stack_floats < 0 || sc->n_slots < 0)
     return fail(RM_E_BADARG, "scene: bad sizes (n_instr=%d n_params=%d)", sc->n_instr, sc->n_params);
-  return RM_OK;
+  return check_static(sc);
 }
 
 struct Launch {
@@ -38,12 +48,29 @@ struct Launch {
   size_t lds;
 };
 
+#ifdef RM_STATIC_CODE
+using G = rm::StaticCfg<RmStaticCode>;
+// static path: parameter block + (backward) one accumulator row per wave for the block reduction
+size_t lds_bytes(const RmScene& sc, int block, bool backward) {
+  size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
+  return 4 * (pb + (backward ? (size_t)(block >> 6) * (sc.n_params + sc.n_derived) : 0) + 4);
+}
+int check_static(const RmScene* sc) {
+  if (sc->n_instr != RmStaticCode::n || sc->n_params != RmStaticCode::n_params ||
+      sc->n_derived != RmStaticCode::n_derived || sc->n_slots != RmStaticCode::n_slots)
+    return fail(RM_E_PROGRAM, "scene does not match the program this library was specialised for");
+  return RM_OK;
+}
+#else
+using G = rm::GenericCfg;
+int check_static(const RmScene*) { return RM_OK; }
 // LDS bytes of the generic path for a block of `block` threads.
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
   size_t per_thread = (size_t)sc.stack_floats + sc.n_slots + (backward ? sc.n_params + sc.n_derived : 0);
   return 4 * (pb + 4 * (size_t)sc.n_instr + per_thread * (block + 1));
 }
+#endif
 
 template <class K>
 int pick_launch(K kernel, const RmScene& sc, bool backward, int max_block, Launch* out) {
@@ -78,8 +105,6 @@ int reduce_partials(const RmScene& sc, const float* partials, int nblocks, float
   return launched("k_reduce_partials");
 }
 
-using G = rm::GenericCfg;
-
 }  // namespace
 
 extern "C" {
@@ -107,6 +132,9 @@ int rm_sdf_forward(const RmScene* scene, const float* points, float* dist, int64
 
 int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad_dist, float* grad_points,
                     float* grad_params, float* partials, int64_t n, void* stream) {
+#ifdef RM_NO_BACKWARD
+  return fail(RM_E_BADARG, "rm_sdf_backward: this specialised library was built forward-only");
+#else
   if (int e = check_scene(scene)) return e;
   if (n <= 0 || !points || !grad_dist || !partials) return fail(RM_E_BADARG, "rm_sdf_backward: null buffer / n<=0");
   Launch L;
@@ -115,6 +143,7 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
   rm::k_sdf_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
   if (int e = launched("k_sdf_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+#endif
 }
 
 int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, float* out_pos, float* traj,
@@ -132,6 +161,9 @@ int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, 
 int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj, const int32_t* nexec,
                       const float* grad_out, float* grad_pos, float* grad_dirs, float* grad_params,
                       float* partials, int64_t n, int32_t steps, void* stream) {
+#ifdef RM_NO_BACKWARD
+  return fail(RM_E_BADARG, "rm_march_backward: this specialised library was built forward-only");
+#else
   if (int e = check_scene(scene)) return e;
   if (n <= 0 || steps < 0 || !dirs || !grad_out || !partials || (steps > 0 && !traj))
     return fail(RM_E_BADARG, "rm_march_backward: bad args");
@@ -142,6 +174,7 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
                                                                    partials, n, steps);
   if (int e = launched("k_march_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+#endif
 }
 
 int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* coords, float* normals,
@@ -159,6 +192,9 @@ int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* 
 int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float* coords, const float* grad_normals,
                         const float* grad_lap, float* grad_coords, float* grad_params, float* partials, int64_t n,
                         void* stream) {
+#ifdef RM_NO_BACKWARD
+  return fail(RM_E_BADARG, "rm_normals_backward: this specialised library was built forward-only");
+#else
   if (int e = check_scene(scene)) return e;
   if (!tetra || n <= 0 || !coords || !partials) return fail(RM_E_BADARG, "rm_normals_backward: bad args");
   Launch L;
@@ -168,6 +204,7 @@ int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float*
                                                                      grad_coords, partials, n);
   if (int e = launched("k_normals_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+#endif
 }
 
 int rm_camera_forward(const RmCamera* cam, const float* orientation, const float* translation, float* out_pos,
@@ -283,6 +320,9 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
                        const float* grad_image, float* grad_params, float* partials, int32_t mode, int32_t steps,
                        int32_t row_begin, int32_t row_end, void* stream) {
+#ifdef RM_NO_BACKWARD
+  return fail(RM_E_BADARG, "rm_render_backward: this specialised library was built forward-only");
+#else
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
   if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL))
     return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (use modes 0 or 4)", mode);
@@ -301,6 +341,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   rm::k_render_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+#endif
 }
 
 /* Host-side validation of a compiled program (host pointer).  The device copy a

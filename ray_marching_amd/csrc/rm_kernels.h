@@ -26,6 +26,7 @@ struct GenericCfg {
   using Prog = RuntimeProgram;
   using SceneT = Scene<Prog, Store>;
   static constexpr bool kStatic = false;
+  static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_derived; }
 
   // returns the scene context; `store` must outlive it
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
@@ -54,6 +55,8 @@ struct StaticCfg {
   using Prog = StaticProgram<Code>;
   using SceneT = Scene<Prog, Store>;
   static constexpr bool kStatic = true;
+  static constexpr int kAcc = Code::n_params + Code::n_derived;
+  static RM_DEV int n_acc(const RmScene&) { return kAcc; }
 
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
     // the parameter block is still staged through LDS (raw + derived), the program is not
@@ -87,9 +90,14 @@ extern __shared__ __attribute__((aligned(16))) float rm_smem[];
 // ---------------------------------------------------------------------------
 // gradient accumulators: zero at start, block-reduce into partials at the end
 // ---------------------------------------------------------------------------
-template <class SceneT>
-RM_DEV void zero_accumulators(const SceneT& sc, int n_acc) {
-  for (int i = 0; i < n_acc; ++i) sc.st->st(sc.acc0 + i, 0.0f);
+template <class Cfg>
+RM_DEV void zero_accumulators(const typename Cfg::SceneT& sc, int n_acc) {
+  if constexpr (Cfg::kStatic) {
+#pragma unroll
+    for (int i = 0; i < Cfg::kAcc; ++i) sc.st->st(sc.acc0 + i, 0.0f);   // constant indices: stays in VGPRs
+  } else {
+    for (int i = 0; i < n_acc; ++i) sc.st->st(sc.acc0 + i, 0.0f);
+  }
 }
 
 // partials[blockIdx.x][n_acc]: deterministic (fixed lane order) sum over the block.
@@ -110,7 +118,8 @@ RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float*
     // registers: butterfly over the wave, then waves through LDS scratch
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
-    for (int i = 0; i < n_acc; ++i) {
+#pragma unroll
+    for (int i = 0; i < Cfg::kAcc; ++i) {
       float v = sc.st->ld(sc.acc0 + i);
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       if (lane == 0) smem_scratch[wave * n_acc + i] = v;
@@ -128,7 +137,7 @@ RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float*
 // scene(query) forward / backward
 // ---------------------------------------------------------------------------
 template <class Cfg>
-__global__ void k_sdf_fwd(RmScene sc, const float* __restrict__ pts, float* __restrict__ dist, int64_t n) {
+__global__ void __launch_bounds__(256) k_sdf_fwd(RmScene sc, const float* __restrict__ pts, float* __restrict__ dist, int64_t n) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
@@ -142,12 +151,12 @@ __global__ void k_sdf_fwd(RmScene sc, const float* __restrict__ pts, float* __re
 }
 
 template <class Cfg>
-__global__ void k_sdf_bwd(RmScene sc, const float* __restrict__ pts, const float* __restrict__ gd,
+__global__ void __launch_bounds__(256) k_sdf_bwd(RmScene sc, const float* __restrict__ pts, const float* __restrict__ gd,
                           float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
-  const int n_acc = sc.n_params + sc.n_derived;
-  zero_accumulators(scene, n_acc);
+  const int n_acc = Cfg::n_acc(sc);
+  zero_accumulators<Cfg>(scene, n_acc);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t i = tile * blockDim.x + threadIdx.x;
@@ -200,7 +209,7 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
 }
 
 template <class Cfg>
-__global__ void k_march_fwd(RmScene sc, const float* __restrict__ pos, const float* __restrict__ dirs,
+__global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const float* __restrict__ pos, const float* __restrict__ dirs,
                             float* __restrict__ out, float* __restrict__ traj, int32_t* __restrict__ nexec_out,
                             int64_t n, int steps, int flags) {
   typename Cfg::Store store;
@@ -237,14 +246,14 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
 }
 
 template <class Cfg>
-__global__ void k_march_bwd(RmScene sc, const float* __restrict__ dirs, const float* __restrict__ traj,
+__global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __restrict__ dirs, const float* __restrict__ traj,
                             const int32_t* __restrict__ nexec, const float* __restrict__ gout,
                             float* __restrict__ gpos, float* __restrict__ gdirs, float* __restrict__ partials,
                             int64_t n, int steps) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
-  const int n_acc = sc.n_params + sc.n_derived;
-  zero_accumulators(scene, n_acc);
+  const int n_acc = Cfg::n_acc(sc);
+  zero_accumulators<Cfg>(scene, n_acc);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int64_t i = tile * blockDim.x + threadIdx.x;
@@ -270,7 +279,7 @@ __global__ void k_march_bwd(RmScene sc, const float* __restrict__ dirs, const fl
 // normals
 // ---------------------------------------------------------------------------
 template <class Cfg>
-__global__ void k_normals_fwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts, float* __restrict__ nrm,
+__global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts, float* __restrict__ nrm,
                               float* __restrict__ lap, int64_t n) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
@@ -326,13 +335,13 @@ RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float 
 }
 
 template <class Cfg>
-__global__ void k_normals_bwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts,
+__global__ void __launch_bounds__(256) k_normals_bwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts,
                               const float* __restrict__ gn, const float* __restrict__ gl,
                               float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
-  const int n_acc = sc.n_params + sc.n_derived;
-  zero_accumulators(scene, n_acc);
+  const int n_acc = Cfg::n_acc(sc);
+  zero_accumulators<Cfg>(scene, n_acc);
   Tetra T = load_tetra(tetra);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -537,7 +546,7 @@ __global__ void k_shade_fwd(ShadeArgs a) {
 }
 
 template <class Cfg>
-__global__ void k_render_fwd(RenderArgs a) {
+__global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store);
   Tetra T = load_tetra(a.tetra);
@@ -644,11 +653,11 @@ __global__ void k_camera_fwd(RmCamera cam, const float* __restrict__ orientation
 
 // VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
 template <class Cfg>
-__global__ void k_render_bwd(RenderArgs a) {
+__global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store);
-  const int n_acc = a.scene.n_params + a.scene.n_derived;
-  zero_accumulators(scene, n_acc);
+  const int n_acc = Cfg::n_acc(a.scene);
+  zero_accumulators<Cfg>(scene, n_acc);
   Tetra T = load_tetra(a.tetra);
   const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
   const int64_t R = (int64_t)a.cam.num_cameras * rows * W;

@@ -31,8 +31,12 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 def _partials(cs: CompiledScene, params, device):
     s, keep = cs.scene_struct(params, device)
-    n = _lib.rm_grad_partials_floats(s, 0)
+    n = cs.lib(True).rm_grad_partials_floats(s, 0)
     return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
+def _ck(cs, code, what):
+    _abi.check(code, what, cs.lib())
 
 
 def default_flags(early_out: bool = True, tile8x8: bool = False) -> int:
@@ -53,7 +57,7 @@ class SDFEval(torch.autograd.Function):
         out = torch.empty(n, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            _abi.check(_lib.rm_sdf_forward(s, _abi.ptr(pts), _abi.ptr(out), n, _abi.current_stream(dev)),
+            _ck(cs, cs.lib().rm_sdf_forward(s, _abi.ptr(pts), _abi.ptr(out), n, _abi.current_stream(dev)),
                        "rm_sdf_forward")
         ctx.cs = cs
         ctx.in_dtype = points.dtype
@@ -73,7 +77,7 @@ class SDFEval(torch.autograd.Function):
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
             part = _partials(cs, prm, dev)
-            _abi.check(_lib.rm_sdf_backward(s, _abi.ptr(pts), _abi.ptr(g), _abi.ptr(gpts), _abi.ptr(gprm),
+            _ck(cs, cs.lib(True).rm_sdf_backward(s, _abi.ptr(pts), _abi.ptr(g), _abi.ptr(gpts), _abi.ptr(gprm),
                                             _abi.ptr(part), n, _abi.current_stream(dev)), "rm_sdf_backward")
         gp = gpts.view(*grad_out.shape[:-1], 3).to(ctx.in_dtype) if gpts is not None else None
         return gprm[: prm.numel()], gp, None
@@ -99,7 +103,7 @@ class March(torch.autograd.Function):
         nexec = torch.empty(n, dtype=torch.int32, device=dev) if need_grad else None
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            _abi.check(_lib.rm_march_forward(s, _abi.ptr(p), _abi.ptr(v), _abi.ptr(out), _abi.ptr(traj),
+            _ck(cs, cs.lib().rm_march_forward(s, _abi.ptr(p), _abi.ptr(v), _abi.ptr(out), _abi.ptr(traj),
                                              _abi.ptr(nexec), n, steps, flags, _abi.current_stream(dev)),
                        "rm_march_forward")
         ctx.cs, ctx.steps, ctx.shape, ctx.in_dtype = cs, steps, shape, pos.dtype
@@ -122,7 +126,7 @@ class March(torch.autograd.Function):
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
             part = _partials(cs, prm, dev)
-            _abi.check(_lib.rm_march_backward(s, _abi.ptr(v), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(g),
+            _ck(cs, cs.lib(True).rm_march_backward(s, _abi.ptr(v), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(g),
                                               _abi.ptr(gpos), _abi.ptr(gdirs), _abi.ptr(gprm), _abi.ptr(part),
                                               n, steps, _abi.current_stream(dev)), "rm_march_backward")
 
@@ -161,7 +165,7 @@ class Normals(torch.autograd.Function):
         lap = torch.empty(n, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            _abi.check(_lib.rm_normals_forward(s, tetra, _abi.ptr(pts), _abi.ptr(nrm), _abi.ptr(lap), n,
+            _ck(cs, cs.lib().rm_normals_forward(s, tetra, _abi.ptr(pts), _abi.ptr(nrm), _abi.ptr(lap), n,
                                                _abi.current_stream(dev)), "rm_normals_forward")
         ctx.cs, ctx.tetra, ctx.in_dtype = cs, tetra, coords.dtype
         ctx.save_for_backward(prm, pts)
@@ -179,7 +183,7 @@ class Normals(torch.autograd.Function):
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
             part = _partials(cs, prm, dev)
-            _abi.check(_lib.rm_normals_backward(s, ctx.tetra, _abi.ptr(pts), _abi.ptr(gn), _abi.ptr(gl),
+            _ck(cs, cs.lib(True).rm_normals_backward(s, ctx.tetra, _abi.ptr(pts), _abi.ptr(gn), _abi.ptr(gl),
                                                 _abi.ptr(gpts), _abi.ptr(gprm), _abi.ptr(part), n,
                                                 _abi.current_stream(dev)), "rm_normals_backward")
         shape = grad_n.shape if grad_n is not None else (*grad_lap.shape[:-1], 3)
@@ -258,7 +262,7 @@ class Render(torch.autograd.Function):
             cam = camera_struct(ray_positions, ray_directions)
             if minmax is not None:
                 _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
-            _abi.check(_lib.rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
+            _ck(cs, cs.lib().rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
                                               _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
                                               _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                               mode, degree, steps, r0, r1, flags, stream), "rm_render_forward")
@@ -285,7 +289,7 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(rp, rd)
             part = _partials(cs, prm, dev)
-            _abi.check(_lib.rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
+            _ck(cs, cs.lib(True).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1],
                                                _abi.current_stream(dev)), "rm_render_backward")
