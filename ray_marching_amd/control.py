@@ -22,7 +22,7 @@ from .rendering.shader import Shader
 class RenderLoop(nn.Module):
     def __init__(self, scene, num_cameras: int = 1, px_width: int = 800, px_height: int = 800,
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
-                 normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = False):
+                 normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True):
         super().__init__()
         self.scene = scene
         self.px_width = px_width

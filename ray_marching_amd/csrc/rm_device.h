@@ -43,9 +43,27 @@ RM_DEV float dot_seq(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RM_DEV V3 cross(V3 a, V3 b) {
   return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-// Correctly rounded sqrt (ATen CPU = IEEE sqrt).  NOTE: hipcc lowers __fsqrt_rn to the bare
-// 1-ulp v_sqrt_f32; sqrtf() is the one that adds the +-1 ulp correction (measured).
-RM_DEV float rm_sqrt(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded sqrt (ATen CPU = IEEE sqrt): v_sqrt_f32 is 1 ulp, so test the two
+// neighbours with exact FMA residuals and step to the one that brackets x (the correction
+// step of LLVM's own f32 sqrt expansion).  0, inf, NaN and negatives fall through unchanged
+// because every comparison with a NaN residual is false.  Unlike sqrtf() the input is not
+// pre-scaled, so for x < 2^-96 (|p| < 1e-14) the residuals underflow and the result may keep
+// v_sqrt's 1-ulp error; 9 instructions instead of 15.  (hipcc lowers __fsqrt_rn to the bare
+// 1-ulp v_sqrt_f32 -- it is NOT correctly rounded; measured, see DESIGN.md.)
+RM_DEV float rm_sqrt(float x) {
+#ifdef RM_LIBM_SQRT
+  return __builtin_sqrtf(x);
+#else
+  float r = __builtin_amdgcn_sqrtf(x);
+  float lo = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1);
+  float hi = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+  float elo = __builtin_fmaf(-lo, r, x);
+  float ehi = __builtin_fmaf(-hi, r, x);
+  r = (elo <= 0.0f) ? lo : r;
+  r = (ehi > 0.0f) ? hi : r;
+  return r;
+#endif
+}
 // ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
 RM_DEV float norm3(V3 a) { return rm_sqrt(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
 RM_DEV float norm2(float a, float b) { return rm_sqrt(__builtin_fmaf(b, b, a * a)); }
@@ -57,10 +75,13 @@ RM_DEV V3 qrot(V3 v, float w, V3 qv) {
 }
 
 // torch semantics helpers ---------------------------------------------------
-RM_DEV float t_relu_keep(float x) { return (x > 0.0f) ? x : 0.0f; }             // x.where(x > 0, 0)
-RM_DEV float t_clamp(float x, float lo, float hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }  // NaN passes
-RM_DEV float t_min(float acc, float d) { return (d < acc || d != d) ? d : acc; }  // NaN-propagating
-RM_DEV float t_max(float acc, float d) { return (d > acc || d != d) ? d : acc; }
+// gfx950 has NaN-propagating v_minimum3_f32 / v_maximum3_f32 (IEEE-754-2019 minimum/maximum),
+// which is exactly torch's min/max/clamp behaviour; v_max_f32 (maxNum) maps NaN to the other
+// operand, which is what x.where(x > 0, 0) does with a NaN.
+RM_DEV float t_relu_keep(float x) { return __builtin_fmaxf(x, 0.0f); }          // x.where(x > 0, 0)
+RM_DEV float t_min(float acc, float d) { return __builtin_elementwise_minimum(acc, d); }  // NaN-propagating
+RM_DEV float t_max(float acc, float d) { return __builtin_elementwise_maximum(acc, d); }
+RM_DEV float t_clamp(float x, float lo, float hi) { return t_min(t_max(x, lo), hi); }     // NaN passes
 RM_DEV float sgn0(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
 RM_DEV float uniform_f(float x) {
@@ -91,12 +112,25 @@ struct RegStore {
   RM_DEV void add(int i, float v) { r[i] += v; }
 };
 
-// Parameter block view (LDS).  Values are wave-uniform; readfirstlane moves them
-// to SGPRs so they ride along as scalar operands.
-struct Params {
+// Parameter block views.  LdsParams reads the staged block where it is needed (generic
+// interpreter: the offset is only known at run time).  RegParams copies the block out of LDS
+// once per thread into wave-uniform registers (readfirstlane -> SGPRs) so a specialised march
+// loop carries no parameter loads at all.
+struct LdsParams {
   const float* p;
-  RM_DEV float operator[](int i) const { return uniform_f(p[i]); }
-  RM_DEV V3 v3(int i) const { return V3{uniform_f(p[i]), uniform_f(p[i + 1]), uniform_f(p[i + 2])}; }
+  RM_DEV float operator[](int i) const { return p[i]; }
+  RM_DEV V3 v3(int i) const { return V3{p[i], p[i + 1], p[i + 2]}; }
+};
+
+template <int N>
+struct RegParams {
+  float v[N > 0 ? N : 1];
+  RM_DEV void load(const float* lds) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = uniform_f(lds[i]);
+  }
+  RM_DEV float operator[](int i) const { return v[i]; }
+  RM_DEV V3 v3(int i) const { return V3{v[i], v[i + 1], v[i + 2]}; }
 };
 
 // --------------------------------------------------------------------------
@@ -113,8 +147,8 @@ struct Fwd {
   bool record; // record every fold/onion input (needed by the reverse sweep)
 };
 
-template <class S>
-RM_DEV void fwd_op(S& s, Params P, int op, int off, int a0, int a1) {
+template <class S, class PT>
+RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
   switch (op) {
     case RM_OP_SPHERE:  // |p| - r
       s.d = norm3(s.p) - P[off];
@@ -217,8 +251,8 @@ RM_DEV V3 safe_unit_scaled(V3 w, float n, float g) {
   return mk3(w.x * s, w.y * s, w.z * s);
 }
 
-template <class S>
-RM_DEV void bwd_op(S& s, Params P, int op, int off, int a0, int a1) {
+template <class S, class PT>
+RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
   const int A = s.acc0;
   switch (op) {
     case RM_OP_SPHERE: {
@@ -378,15 +412,15 @@ struct Ins {
 struct RuntimeProgram {
   const int4* code;  // LDS
   int n;
-  template <class S>
-  RM_DEV void forward(S& s, Params P) const {
+  template <class S, class PT>
+  RM_DEV void forward(S& s, const PT& P) const {
     for (int pc = 0; pc < n; ++pc) {
       int4 w = code[pc];
       fwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
     }
   }
-  template <class S>
-  RM_DEV void backward(S& s, Params P) const {
+  template <class S, class PT>
+  RM_DEV void backward(S& s, const PT& P) const {
     for (int pc = n - 1; pc >= 0; --pc) {
       int4 w = code[pc];
       bwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
@@ -397,33 +431,33 @@ struct RuntimeProgram {
 // Compile-time program: Code::code[] is constexpr, recursion unrolls it.
 template <class Code>
 struct StaticProgram {
-  template <int PC, class S>
-  RM_DEV void fwd_from(S& s, Params P) const {
+  template <int PC, class S, class PT>
+  RM_DEV void fwd_from(S& s, const PT& P) const {
     if constexpr (PC < Code::n) {
       constexpr Ins i = Code::code[PC];
       fwd_op(s, P, i.op, i.off, i.a0, i.a1);
       fwd_from<PC + 1>(s, P);
     }
   }
-  template <int PC, class S>
-  RM_DEV void bwd_from(S& s, Params P) const {
+  template <int PC, class S, class PT>
+  RM_DEV void bwd_from(S& s, const PT& P) const {
     if constexpr (PC >= 0) {
       constexpr Ins i = Code::code[PC];
       bwd_op(s, P, i.op, i.off, i.a0, i.a1);
       bwd_from<PC - 1>(s, P);
     }
   }
-  template <class S>
-  RM_DEV void forward(S& s, Params P) const { fwd_from<0>(s, P); }
-  template <class S>
-  RM_DEV void backward(S& s, Params P) const { bwd_from<Code::n - 1>(s, P); }
+  template <class S, class PT>
+  RM_DEV void forward(S& s, const PT& P) const { fwd_from<0>(s, P); }
+  template <class S, class PT>
+  RM_DEV void backward(S& s, const PT& P) const { bwd_from<Code::n - 1>(s, P); }
 };
 
 // Scene evaluation context shared by all kernels of one block.
-template <class Prog, class Store>
+template <class Prog, class Store, class PT>
 struct Scene {
   Prog prog;
-  Params P;
+  PT P;
   Store* st;
   int tape0;   // store index of tape slot 0 (= stack_floats)
   int acc0;    // store index of gradient accumulator 0 (= stack_floats + n_slots)

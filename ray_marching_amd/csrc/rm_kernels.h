@@ -14,6 +14,8 @@
 
 #include "rm_device.h"
 
+#include <type_traits>
+
 namespace rm {
 
 // ---------------------------------------------------------------------------
@@ -24,7 +26,7 @@ namespace rm {
 struct GenericCfg {
   using Store = LdsStore;
   using Prog = RuntimeProgram;
-  using SceneT = Scene<Prog, Store>;
+  using SceneT = Scene<Prog, Store, LdsParams>;
   static constexpr bool kStatic = false;
   static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_derived; }
 
@@ -53,7 +55,11 @@ struct StaticCfg {
   static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_derived;
   using Store = RegStore<kStoreN>;
   using Prog = StaticProgram<Code>;
-  using SceneT = Scene<Prog, Store>;
+  // small parameter blocks ride in registers; big ones (config 5: 381 floats) stay in LDS
+  static constexpr int kParamFloats = Code::n_params + Code::n_derived;
+  static constexpr bool kRegParams = kParamFloats <= 64;
+  using PT = std::conditional_t<kRegParams, RegParams<kParamFloats>, LdsParams>;
+  using SceneT = Scene<Prog, Store, PT>;
   static constexpr bool kStatic = true;
   static constexpr int kAcc = Code::n_params + Code::n_derived;
   static RM_DEV int n_acc(const RmScene&) { return kAcc; }
@@ -77,7 +83,7 @@ struct StaticCfg {
     }
     __syncthreads();
     SceneT s;
-    s.P.p = s_params;
+    if constexpr (kRegParams) s.P.load(s_params); else s.P.p = s_params;
     s.st = &store;
     s.tape0 = Code::stack_floats;
     s.acc0 = Code::stack_floats + Code::n_slots;
