@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL tile gather")
     ap.add_argument("--no-early-out", action="store_true")
     ap.add_argument("--linear-waves", action="store_true", help="64x1 pixels per wave instead of 8x8 tiles")
+    ap.add_argument("--static-tiles", action="store_true", help="static tile striding instead of the atomic tile queues")
     ap.add_argument("--camera-z", type=float, default=-3.0, help="camera position (0,0,z); SURVEY 8d uses -3 and +1")
     ap.add_argument("--skip-backward", action="store_true")
     return ap.parse_args()
@@ -160,7 +161,7 @@ def main():
     h_total = H_TILE * world
     loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=h_total, focal_length=PX * H_TILE,
                       sensor_width=PX * W, sensor_height=PX * h_total, normals_eps=EPS,
-                      early_out=not args.no_early_out, tile8x8=not args.linear_waves).to(dev)
+                      early_out=not args.no_early_out, tile8x8=not args.linear_waves, dynamic_tiles=not args.static_tiles).to(dev)
     from ray_marching_amd.compiler import compiled_for
     specialised = compiled_for(loop.scene).specialised
     rows = (rank * H_TILE, (rank + 1) * H_TILE)
@@ -246,6 +247,7 @@ def main():
                                    "frames per step, fp32", "frames_per_step": len(MODES),
                        "rays_per_frame": rays_per_frame, "camera": [0.0, 0.0, args.camera_z],
                        "early_out": not args.no_early_out, "wave_tile": "64x1" if args.linear_waves else "8x8",
+                       "tile_schedule": "static stride" if args.static_tiles else "64 atomic queues + stealing",
                        "kernels": "per-scene specialised (StaticCfg)" if specialised else "generic LDS interpreter",
                        "parallelism": f"row-tiles x{world}" + (" + RCCL gather" if gather else "")},
             "ray_sdf_evals_per_s": value * 1e6 * (STEPS_MARCH + 6),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 3
+#define RM_ABI_VERSION 5
 
 enum {
   RM_OK = 0,
@@ -96,10 +96,20 @@ enum {
 
 /* flags */
 enum {
-  RM_FLAG_EARLY_OUT = 1,   /* wave-uniform exit once every ray of the wave sits on a bit-exact
-                              fixed point / 2-cycle of the march map (results unchanged) */
-  RM_FLAG_TILE8X8 = 2      /* a wave covers an 8x8 pixel tile instead of 64 pixels of one row */
+  RM_FLAG_EARLY_OUT = 1,   /* wave-uniform exit once every ray of the wave is in a proven bit-exact
+                              cycle of the march map (results unchanged) */
+  RM_FLAG_TILE8X8 = 2,     /* a wave covers an 8x8 pixel tile instead of 64 pixels of one row */
+  RM_FLAG_DYNAMIC_TILES = 4 /* waves draw tiles from the workspace's atomic tile queues instead
+                              of a static stride */
 };
+
+/* Workspace ("minmax") layout, uint32 words, prepared by rm_minmax_init before every launch
+ * that uses it: [0] global min, [1] global max (order-preserving encoding), [2] NaN flag,
+ * [RM_WORK_QUEUE_BASE + q*RM_WORK_QUEUE_STRIDE] tile counter of queue q. */
+#define RM_WORK_QUEUES 64
+#define RM_WORK_QUEUE_STRIDE 32
+#define RM_WORK_QUEUE_BASE 64
+#define RM_WORK_WORDS (RM_WORK_QUEUE_BASE + RM_WORK_QUEUES * RM_WORK_QUEUE_STRIDE)
 
 int rm_abi_version(void);
 const char* rm_last_error(void);
@@ -145,8 +155,9 @@ int rm_camera_forward(const RmCamera* cam, const float* orientation /*device [N,
  * normals/laplacian -> shader, rows [row_begin,row_end) of every camera.
  *   image   : device [N,rows,W,3] fp32.
  *   p_final : nullable [N,rows,W,3]; traj: nullable [steps,N*rows*W,3]; nexec nullable.
- *   minmax  : device uint32[4], required for modes 1,2,5 (global min/max, shader.py:35-36,
- *             52-53, 84).  The kernel leaves the un-normalised value in `image` and folds
+ *   minmax  : device uint32[RM_WORK_WORDS] prepared by rm_minmax_init.  Holds the tile queues of
+ *             RM_FLAG_DYNAMIC_TILES (NULL = static striding).  Words 0-2 are required for modes 1,2,5
+ *             (global min/max, shader.py:35-36, 52-53, 84).  The kernel leaves the un-normalised value in `image` and folds
  *             its min/max into minmax; rm_shade_finish() then normalises.  Between the two
  *             calls a multi-GPU host all-reduces minmax (rm_minmax_* helpers).
  *   cmap    : device fp32 [cmap_size,3], required for modes 6,7.
@@ -158,7 +169,8 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
                       int32_t mode, int32_t degree, int32_t steps,
                       int32_t row_begin, int32_t row_end, int32_t flags, void* stream);
 
-/* minmax helpers: init to (+inf, -inf, no-NaN); decode to two floats {lo, hi};
+/* workspace helpers: init (min=+inf, max=-inf, no NaN, all tile counters 0; the buffer holds
+ * RM_WORK_WORDS uint32); decode to two floats {lo, hi};
  * encode two floats back (after a host-side all-reduce). */
 int rm_minmax_init(uint32_t* minmax /*device*/, void* stream);
 int rm_minmax_decode(const uint32_t* minmax, float* lohi /*device [2]*/, void* stream);
@@ -176,12 +188,15 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
                      int64_t n_pixels, int64_t pixels_per_camera, void* stream);
 
 /* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
- * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten. */
+ * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
+ * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
+ * flags: pass the RM_FLAG_TILE8X8 choice of the forward call. */
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                        const float* orientation, const float* translation,
                        const float* traj, const int32_t* nexec, const float* p_final,
-                       const float* grad_image, float* grad_params, float* partials,
-                       int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, void* stream);
+                       const float* grad_image, float* grad_params, float* partials, uint32_t* work,
+                       int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags,
+                       void* stream);
 
 /* Host-side check of a compiled program BEFORE it is uploaded (host pointer):
  * opcode range, parameter/slot/derived offsets inside their blocks, balanced

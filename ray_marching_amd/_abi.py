@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 5
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
 
@@ -19,7 +19,8 @@ OP_UNION_BEGIN, OP_FOLD_MIN, OP_UNION_END = 9, 10, 11
 OP_SMOOTH_BEGIN, OP_FOLD_LSE, OP_SMOOTH_END = 12, 13, 14
 OP_ROUND, OP_ONION = 15, 16
 
-FLAG_EARLY_OUT, FLAG_TILE8X8 = 1, 2
+FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES = 1, 2, 4
+WORK_WORDS = 64 + 64 * 32   # RM_WORK_WORDS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 
 
@@ -65,8 +66,8 @@ _SIGNATURES = {
     "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
-                                     _P, _P, _P, _P, _P, _P,
-                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+                                     _P, _P, _P, _P, _P, _P, _P,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

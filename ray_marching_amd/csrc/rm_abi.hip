@@ -250,17 +250,13 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
   Launch L;
   if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, 256, &L)) return e;
-  int64_t tiles;
+  int64_t wave_tiles;
   {
     const int W = cam->width, rows = row_end - row_begin;
-    if (flags & RM_FLAG_TILE8X8) {
-      int64_t waves = (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3);
-      int wpb = L.block >> 6;
-      tiles = (waves + wpb - 1) / wpb;
-    } else {
-      tiles = ((int64_t)cam->num_cameras * rows * W + L.block - 1) / L.block;
-    }
+    wave_tiles = (flags & RM_FLAG_TILE8X8) ? (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3)
+                                           : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
+  int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = grid_for(tiles, kMaxBlocks);
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   return launched("k_render_fwd");
@@ -268,7 +264,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
 
 int rm_minmax_init(uint32_t* minmax, void* stream) {
   if (!minmax) return fail(RM_E_BADARG, "rm_minmax_init: null");
-  rm::k_minmax_init<<<1, 1, 0, (hipStream_t)stream>>>(minmax);
+  rm::k_minmax_init<<<1, 256, 0, (hipStream_t)stream>>>(minmax);
   return launched("k_minmax_init");
 }
 
@@ -318,8 +314,8 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
 
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
-                       const float* grad_image, float* grad_params, float* partials, int32_t mode, int32_t steps,
-                       int32_t row_begin, int32_t row_end, void* stream) {
+                       const float* grad_image, float* grad_params, float* partials, uint32_t* work, int32_t mode,
+                       int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, void* stream) {
 #ifdef RM_NO_BACKWARD
   return fail(RM_E_BADARG, "rm_render_backward: this specialised library was built forward-only");
 #else
@@ -332,12 +328,17 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
-  a.grad_image = grad_image; a.partials = partials;
-  a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = 0;
+  a.grad_image = grad_image; a.partials = partials; a.minmax = work;
+  a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES);
   Launch L;
   if (int e = pick_launch(rm::k_render_bwd<G>, *scene, true, 128, &L)) return e;
-  int64_t n = (int64_t)cam->num_cameras * (row_end - row_begin) * cam->width;
-  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  int64_t wave_tiles;
+  {
+    const int W = cam->width, rows = row_end - row_begin;
+    wave_tiles = (flags & RM_FLAG_TILE8X8) ? (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3)
+                                           : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
+  }
+  int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), kMaxBlocksBwd);
   rm::k_render_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);

@@ -185,30 +185,52 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 }
 
 // SDFMarcher.forward (ray_marching.py:78-84): p <- f(p)*v + p, `steps` times.
-// Early-out (bit-exact): the march map is a pure function of p, so once
-// p_{i+1} == p_i (fixed point) or p_{i+1} == p_{i-1} (2-cycle) bitwise, every later
-// iterate is known; the wave leaves when ALL its rays are in that state.  With a
-// trajectory being recorded only the fixed-point exit is taken (p_j = p_final for
-// j >= nexec).
+//
+// Early-out (bit-exact).  The march map is a pure function of p (v is fixed per ray), so a
+// repeated state proves a cycle: if p_{i+1} equals a remembered earlier iterate p_s bitwise,
+// every later iterate is p_{s + ((j - s) mod lambda)} with lambda = i + 1 - s.  Each lane keeps
+// one snapshot, refreshed at power-of-two steps (Brent's cycle finder), plus the immediate
+// fixed-point test p_{i+1} == p_i (lambda = 1).  Near a surface fp32 iterates stop moving or
+// hop between a few neighbouring values, so after convergence every ray is in such a cycle
+// (measured: without the snapshot test 30% of wave tiles ran all 128 steps of config 2).
+// The wave leaves when ALL 64 rays have a known period; each lane is then advanced by
+// (remaining mod lambda) < lambda further steps so it lands on exactly the iterate the full
+// loop would have produced.  With a trajectory being recorded (backward) only the fixed point
+// exit is taken (p_j = p_final for j >= nexec).
 template <class SceneT>
 RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* traj, int64_t traj_stride,
                 int64_t ray, bool live, int& nexec) {
-  V3 prev = p;
+  V3 snap = p;          // remembered iterate p_s
+  int snap_step = 0;    // s
+  int next_snap = 1;    // refresh the snapshot when the step index reaches this (1, 2, 4, ...)
+  int lambda = 0;       // cycle length of this ray, 0 = not known yet
   nexec = steps;
   for (int i = 0; i < steps; ++i) {
     if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
     float f = scene.eval(p);
     V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
     if (early) {
-      bool fixed = same_bits(pn, p);
-      bool settled = traj ? fixed : (fixed | same_bits(pn, prev));
-      if (__all(settled)) {
-        int remaining = steps - (i + 1);
+      if (lambda == 0) {
+        if (same_bits(pn, p)) lambda = 1;
+        else if (!traj && same_bits(pn, snap)) lambda = i + 1 - snap_step;
+      }
+      if (__all(lambda > 0)) {
         nexec = i + 1;
-        return (remaining & 1) ? p : pn;  // fixed rays: p == pn; 2-cycles: parity picks the phase
+        int need = (steps - (i + 1)) % lambda;    // further steps this lane still has to take
+        p = pn;
+        while (__any(need > 0)) {                 // < max lambda iterations; lanes freeze when done
+          float g = scene.eval(p);
+          V3 q = mk3(g * v.x + p.x, g * v.y + p.y, g * v.z + p.z);
+          if (need > 0) p = q;
+          --need;
+        }
+        return p;
+      }
+      if (i + 1 == next_snap) {                   // wave-uniform: i and next_snap are scalars
+        if (lambda == 0) { snap = pn; snap_step = i + 1; }
+        next_snap <<= 1;
       }
     }
-    prev = p;
     p = pn;
   }
   return p;
@@ -384,24 +406,29 @@ struct RenderArgs {
   float* partials;
 };
 
-// ray index of this lane inside the row band: R = N * rows * W rays, local index li.
-// With RM_FLAG_TILE8X8 the 64 lanes of a wave cover an 8x8 pixel tile (better
-// convergence coherence for the wave-uniform early-out); otherwise 64 pixels of a row.
-RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t tile, int& cam, int& row, int& col) {
+// Work decomposition of a frame: a *wave tile* is 64 rays handled by one wavefront --
+// an 8x8 pixel tile (RM_FLAG_TILE8X8, better convergence coherence for the wave-uniform
+// early-out) or 64 consecutive pixels of the row-major band.
+RM_DEV int64_t wave_tiles(const RenderArgs& a) {
   const int W = a.cam.width, rows = a.row_end - a.row_begin;
+  if (a.flags & RM_FLAG_TILE8X8) return (int64_t)a.cam.num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3);
+  return ((int64_t)a.cam.num_cameras * rows * W + 63) >> 6;
+}
+
+RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t wave_tile, int& cam, int& row, int& col) {
+  const int W = a.cam.width, rows = a.row_end - a.row_begin;
+  const int lane = threadIdx.x & 63;
   if (a.flags & RM_FLAG_TILE8X8) {
     const int tw = (W + 7) >> 3, th = (rows + 7) >> 3;
-    int64_t wave_global = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
     int64_t per_cam = (int64_t)tw * th;
-    cam = (int)(wave_global / per_cam);
-    int64_t t = wave_global - (int64_t)cam * per_cam;
+    cam = (int)(wave_tile / per_cam);
+    int64_t t = wave_tile - (int64_t)cam * per_cam;
     int ty = (int)(t / tw), tx = (int)(t - (int64_t)ty * tw);
     row = ty * 8 + (lane >> 3);
     col = tx * 8 + (lane & 7);
     return cam < a.cam.num_cameras && row < rows && col < W;
   }
-  int64_t li = tile * blockDim.x + threadIdx.x;
+  int64_t li = wave_tile * 64 + lane;
   int64_t per_cam = (int64_t)rows * W;
   cam = (int)(li / per_cam);
   int64_t r = li - (int64_t)cam * per_cam;
@@ -410,15 +437,70 @@ RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t tile, int& cam, int& row, i
   return cam < a.cam.num_cameras;
 }
 
-RM_DEV int64_t render_tiles(const RenderArgs& a, int block) {
-  const int W = a.cam.width, rows = a.row_end - a.row_begin;
-  if (a.flags & RM_FLAG_TILE8X8) {
-    int64_t waves = (int64_t)a.cam.num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3);
-    int wpb = block >> 6;
-    return (waves + wpb - 1) / wpb;
+// Dynamic tile distribution.  The bit-exact early-out makes tile cost vary ~6x (config 2: 30% of
+// the wave tiles -- rays sliding along the side walls -- need all 128 steps, the rest ~20) and
+// a static stride of 4 tiles per wave ends with a tail ~2.4x the mean.  A single atomic counter
+// is no cure: same-address returning atomics retire at 12-16 ns each chip-wide (measured,
+// profiles/micro/atomic_bench.hip), i.e. 0.5 ms for the 32k tiles of one frame.  So the tiles
+// are dealt round-robin into RM_WORK_QUEUES counters on separate 128-B lines; a wave drains
+// its home queue and then steals from the next non-empty one.  Emptiness of all queues is read
+// with ONE 64-lane agent-scope load (lane l reads counter l).  Counters only grow, every tile
+// index is handed out exactly once, and a wave leaves when every counter has passed its queue's
+// size, so the grid always drains.
+RM_DEV uint32_t queue_size(int64_t ntiles, int q) {
+  return (q < ntiles) ? (uint32_t)((ntiles - q + RM_WORK_QUEUES - 1) / RM_WORK_QUEUES) : 0u;
+}
+
+RM_DEV int64_t grab_wave_tile(uint32_t* work, int64_t ntiles, int& q) {
+  const int lane = threadIdx.x & 63;
+  uint32_t* ctr = work + RM_WORK_QUEUE_BASE;
+  for (int attempt = 0; attempt < 4 * RM_WORK_QUEUES; ++attempt) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&ctr[q * RM_WORK_QUEUE_STRIDE], 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t < queue_size(ntiles, q)) return (int64_t)q + (int64_t)t * RM_WORK_QUEUES;
+    // home queue is empty: look at all of them at once
+    uint32_t c = __hip_atomic_load(&ctr[lane * RM_WORK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long avail = __ballot(c < queue_size(ntiles, lane));
+    if (avail == 0ull) return -1;
+    unsigned long long rot = (q == 63) ? avail : ((avail >> (q + 1)) | (avail << (63 - q)));
+    q = (q + 1 + __builtin_ctzll(rot)) & 63;
   }
-  int64_t R = (int64_t)a.cam.num_cameras * rows * W;
-  return (R + block - 1) / block;
+  // not reached in practice; finish with a definitive sweep so no tile can be dropped
+  for (int k = 0; k < RM_WORK_QUEUES; ++k) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&ctr[k * RM_WORK_QUEUE_STRIDE], 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t < queue_size(ntiles, k)) { q = k; return (int64_t)k + (int64_t)t * RM_WORK_QUEUES; }
+  }
+  return -1;
+}
+
+struct TileCursor {
+  int64_t tile;
+  int q;
+};
+
+RM_DEV TileCursor first_wave_tile(const RenderArgs& a, int64_t ntiles) {
+  TileCursor c;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  c.q = (int)(wave & (RM_WORK_QUEUES - 1));
+  if (a.minmax && (a.flags & RM_FLAG_DYNAMIC_TILES)) {
+    c.tile = grab_wave_tile(a.minmax, ntiles, c.q);
+    if (c.tile < 0) c.tile = ntiles;
+  } else {
+    c.tile = wave;
+  }
+  return c;
+}
+
+RM_DEV void next_wave_tile(const RenderArgs& a, int64_t ntiles, TileCursor& c) {
+  if (a.minmax && (a.flags & RM_FLAG_DYNAMIC_TILES)) {
+    c.tile = grab_wave_tile(a.minmax, ntiles, c.q);
+    if (c.tile < 0) c.tile = ntiles;
+  } else {
+    c.tile += (int64_t)gridDim.x * (blockDim.x >> 6);
+  }
 }
 
 RM_DEV Pose load_pose(const float* orientation, const float* translation, int cam) {
@@ -561,10 +643,10 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   const bool early = a.flags & RM_FLAG_EARLY_OUT;
   float lo = __builtin_inff(), hi = -__builtin_inff();
   bool saw_nan = false;
-  int64_t ntiles = render_tiles(a, blockDim.x);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int64_t ntiles = wave_tiles(a);
+  for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
     int cam, row, col;
-    bool live = ray_of_lane(a, tile, cam, row, col);
+    bool live = ray_of_lane(a, tc.tile, cam, row, col);
     if (!live) { cam = 0; row = 0; col = 0; }
     int64_t li = ((int64_t)cam * rows + row) * W + col;                  // index in the band outputs
     int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;     // index in the camera buffers
@@ -621,8 +703,11 @@ __global__ void k_shade_finish(float* __restrict__ image, int64_t n, const uint3
   }
 }
 
+// workspace: words 0-2 global min / max / NaN flag, the rest zero (tile queue counters)
 __global__ void k_minmax_init(uint32_t* mm) {
-  mm[0] = f2ord(__builtin_inff()); mm[1] = f2ord(-__builtin_inff()); mm[2] = 0u; mm[3] = 0u;
+  for (int i = threadIdx.x; i < RM_WORK_WORDS; i += blockDim.x) mm[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) { mm[0] = f2ord(__builtin_inff()); mm[1] = f2ord(-__builtin_inff()); }
 }
 __global__ void k_minmax_decode(const uint32_t* mm, float* lohi) {
   float nanv = __builtin_nanf("");
@@ -667,10 +752,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   Tetra T = load_tetra(a.tetra);
   const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
   const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
-  int64_t ntiles = render_tiles(a, blockDim.x);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int64_t ntiles = wave_tiles(a);
+  for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
     int cam, row, col;
-    bool live = ray_of_lane(a, tile, cam, row, col);
+    bool live = ray_of_lane(a, tc.tile, cam, row, col);
     if (!live) { cam = 0; row = 0; col = 0; }
     int64_t li = ((int64_t)cam * rows + row) * W + col;
     int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;

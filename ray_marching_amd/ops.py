@@ -39,8 +39,9 @@ def _ck(cs, code, what):
     _abi.check(code, what, cs.lib())
 
 
-def default_flags(early_out: bool = True, tile8x8: bool = False) -> int:
-    return (_abi.FLAG_EARLY_OUT if early_out else 0) | (_abi.FLAG_TILE8X8 if tile8x8 else 0)
+def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False) -> int:
+    return ((_abi.FLAG_EARLY_OUT if early_out else 0) | (_abi.FLAG_TILE8X8 if tile8x8 else 0) |
+            (_abi.FLAG_DYNAMIC_TILES if dynamic_tiles else 0))
 
 
 # --------------------------------------------------------------------------
@@ -255,18 +256,17 @@ class Render(torch.autograd.Function):
         p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if need_grad else None
         traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (need_grad and steps > 0) else None
         nexec = torch.empty(R, dtype=torch.int32, device=dev) if need_grad else None
-        minmax = torch.empty(4, dtype=torch.int32, device=dev) if mode in _GLOBAL_MODES else None
+        minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)   # global min/max words + dynamic tile counter
         with torch.cuda.device(dev):
             stream = _abi.current_stream(dev)
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(ray_positions, ray_directions)
-            if minmax is not None:
-                _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
+            _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
             _ck(cs, cs.lib().rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
                                               _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
                                               _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                               mode, degree, steps, r0, r1, flags, stream), "rm_render_forward")
-            if minmax is not None:
+            if mode in _GLOBAL_MODES:
                 if allreduce_minmax is not None:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
                     _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
@@ -276,7 +276,7 @@ class Render(torch.autograd.Function):
                            "rm_shade_finish")
         if need_grad:
             ctx.save_for_backward(prm, q, t, ray_positions, ray_directions, p_final, traj, nexec)
-            ctx.cs, ctx.tetra, ctx.mode, ctx.steps, ctx.rows = cs, tetra, mode, steps, (r0, r1)
+            ctx.cs, ctx.tetra, ctx.mode, ctx.steps, ctx.rows, ctx.flags = cs, tetra, mode, steps, (r0, r1), flags
         return image
 
     @staticmethod
@@ -289,8 +289,11 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(rp, rd)
             part = _partials(cs, prm, dev)
+            work = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)
+            stream = _abi.current_stream(dev)
+            _abi.check(_lib.rm_minmax_init(_abi.ptr(work), stream), "rm_minmax_init")
             _ck(cs, cs.lib(True).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
-                                               _abi.ptr(part), ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1],
-                                               _abi.current_stream(dev)), "rm_render_backward")
+                                               _abi.ptr(part), _abi.ptr(work), ctx.mode, ctx.steps, ctx.rows[0],
+                                               ctx.rows[1], ctx.flags, stream), "rm_render_backward")
         return (gprm[: prm.numel()],) + (None,) * 13

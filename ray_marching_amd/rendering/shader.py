@@ -71,7 +71,7 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
             raise ValueError("tangent / spin shaders need a colormap")
         cm = _f32c(cmap).to(dev)
     image = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    minmax = torch.empty(4, dtype=torch.int32, device=dev) if mode in _GLOBAL else None
+    minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev) if mode in _GLOBAL else None
     with torch.cuda.device(dev):
         stream = _abi.current_stream(dev)
         if minmax is not None:
