@@ -1,0 +1,115 @@
+"""Row-tile sharding of a frame over the GPUs of one node.
+
+Rays are independent, so a frame is split into contiguous pixel-row bands, one per rank (one
+process per GPU, ``torch.distributed`` backend "nccl" = RCCL over xGMI).  The scene block is
+replicated (a few hundred bytes).  The only exchanges are:
+
+* a 2-float all-reduce(min/max) between the two passes of the globally normalised shaders
+  (modes 1, 2, 5; reference rendering/shader.py:35-36, 52-53, 84);
+* the final gather of the image tiles (to one rank, or all-gather);
+* a P-float all-reduce(sum) of the scene-parameter gradients in training.
+
+Per-pixel shaders (modes 0, 3, 4, 6, 7) involve no exchange and the reassembled frame is
+bit-identical to a single-GPU render (tests/test_gpu_parity.py::test_full_size_properties).
+
+``render_fn`` is the band renderer: by default the HIP ``RenderLoop``.  Tests inject a CPU
+function so the sharding / collective logic is exercised with gloo on machines without GPUs.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def row_band(height: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous band [r0, r1) of ``rank``: ceil(height / world) rows each, the last ones shorter
+    (possibly empty) so that every gathered tile can be padded to one common size."""
+    per = -(-height // world)
+    r0 = min(rank * per, height)
+    return r0, min(r0 + per, height)
+
+
+class RowTileRenderer:
+    def __init__(self, loop=None, group=None, render_fn: Optional[Callable] = None, height: Optional[int] = None):
+        if loop is None and render_fn is None:
+            raise ValueError("need a RenderLoop or a render_fn")
+        self.loop = loop
+        self.group = group
+        self.render_fn = render_fn if render_fn is not None else self._hip_band
+        self.height = height if height is not None else loop.px_height
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    # -- default band renderer: the fused HIP frame kernel on this rank's rows -------------
+    def _hip_band(self, orientations, translations, mode, degree, steps, rows, allreduce_minmax):
+        return self.loop(orientations, translations, mode, degree, steps, rows=rows,
+                         allreduce_minmax=allreduce_minmax)
+
+    # -- global min/max of the normalised shaders -------------------------------------------
+    def _allreduce_minmax(self, lohi: torch.Tensor):
+        """lohi = [min, max] of this rank's band, reduced in place over the group."""
+        if self.world == 1:
+            return
+        lo, hi = lohi[:1].clone(), lohi[1:].clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        lohi[0:1].copy_(lo)
+        lohi[1:2].copy_(hi)
+
+    def band(self):
+        return row_band(self.height, self.rank, self.world)
+
+    def render_band(self, orientations, translations, mode: int = 0, degree: int = 1, marching_steps: int = 32):
+        """This rank's tile [N, rows, W, 3] (rows may be 0 for surplus ranks)."""
+        r0, r1 = self.band()
+        if r1 <= r0:
+            return None
+        return self.render_fn(orientations, translations, mode, degree, marching_steps, (r0, r1),
+                              self._allreduce_minmax)
+
+    def render(self, orientations, translations, mode: int = 0, degree: int = 1, marching_steps: int = 32,
+               dst: Optional[int] = 0, like: Optional[torch.Tensor] = None):
+        """Render this rank's band and gather the frame.  ``dst=None`` all-gathers (every rank gets
+        the frame); otherwise only rank ``dst`` returns it and the others return None."""
+        tile = self.render_band(orientations, translations, mode, degree, marching_steps)
+        if self.world == 1:
+            return tile
+        per = -(-self.height // self.world)
+        if tile is None:
+            # surplus rank still takes part in the collectives (incl. the min/max all-reduce)
+            if mode % 8 in (1, 2, 5):
+                lohi = torch.tensor([float("inf"), float("-inf")], device=like.device)
+                self._allreduce_minmax(lohi)
+            tile = like.new_zeros((like.shape[0], 0, like.shape[2], 3))
+        n, rows, w, c = tile.shape
+        padded = tile if rows == per else torch.cat([tile, tile.new_zeros((n, per - rows, w, c))], dim=1)
+        padded = padded.contiguous()
+        if dst is None:
+            parts = [torch.empty_like(padded) for _ in range(self.world)]
+            dist.all_gather(parts, padded, group=self.group)
+        else:
+            parts = [torch.empty_like(padded) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(padded, parts, dst=dst, group=self.group)
+            if self.rank != dst:
+                return None
+        frame = torch.cat(parts, dim=1)[:, : self.height]
+        return frame
+
+
+def all_reduce_gradients(module: torch.nn.Module, group=None):
+    """Sum the scene-parameter gradients over the ranks (each rank back-propagated the loss of
+    its own band).  One flat P-float all-reduce."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[o:o + n].view_as(p).clone()
+        o += n

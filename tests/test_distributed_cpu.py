@@ -1,0 +1,132 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo groups drive RowTileRenderer with an oracle band
+renderer injected in place of the HIP one.  Checks band arithmetic, the min/max all-reduce
+hook, gather / all-gather with ragged bands, and the gradient all-reduce."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import sdf_oracle as O
+
+PX, EPS = 3.45e-6, 5e-2
+H, W, STEPS = 22, 24, 24      # 22 rows: ragged over 3 ranks (8, 8, 6) and over 4 (6, 6, 6, 4)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_band_renderer(spec, bufs, q_full, t_full):
+    """Band renderer with the HIP RenderLoop's contract: rows=(r0,r1), two-pass global modes."""
+    def render_fn(orientations, translations, mode, degree, steps, rows, allreduce_minmax):
+        r0, r1 = rows
+        band = tuple(b[:, r0:r1].contiguous() for b in bufs)
+        mode = mode % 8
+        if mode not in (1, 2, 5):
+            return O.render(spec, band, orientations, translations, mode, degree, steps, EPS)
+        _, aux = O.render(spec, band, orientations, translations, 0, degree, steps, EPS, return_aux=True)
+        if mode == 5:
+            raw = aux["lap"]
+            lohi = torch.stack([raw.abs().min(), raw.abs().max()])
+            allreduce_minmax(lohi)
+            img = ((raw / lohi[1]) * (-1) + 1).div(2).clamp(0, 1).pow(1 / 2.33)
+        else:
+            x = (aux["pos"] - aux["p"]).norm(dim=-1, keepdim=True) if mode == 1 else aux["dist"]
+            raw = x.clamp(1e-2, float("inf")).log()
+            lohi = torch.stack([raw.min(), raw.max()])
+            allreduce_minmax(lohi)
+            img = ((raw - lohi[0]) / (lohi[1] - lohi[0])).pow(1 / 2.33)
+        return img.expand(-1, r1 - r0, W, 3)
+    return render_fn
+
+
+def _worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ray_marching_amd.distributed import RowTileRenderer, all_reduce_gradients, row_band
+        torch.set_num_threads(1)
+        spec = O.scene_test2()
+        bufs = O.camera_buffers(1, W, H, PX * H, PX * W, PX * H)
+        q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -3.0]])
+        r = RowTileRenderer(render_fn=_oracle_band_renderer(spec, bufs, q, t), height=H)
+        assert r.band() == row_band(H, rank, world)
+        like = torch.empty(1, 1, W, 3)
+        out = {}
+        for mode in (0, 4, 1, 2, 5):
+            with torch.no_grad():
+                frame = r.render(q, t, mode, 1, STEPS, dst=0, like=like)
+                every = r.render(q, t, mode, 1, STEPS, dst=None, like=like)
+            assert (frame is not None) == (rank == 0)
+            assert every.shape == (1, H, W, 3)
+            if rank == 0:
+                assert torch.equal(frame, every)
+                out[mode] = frame
+        # gradient all-reduce: each rank differentiates the loss of its own band
+        gspec = O.map_spec(O.scene_test1_closed(), lambda x: x.clone().requires_grad_(True))
+        r0, r1 = r.band()
+        band = tuple(b[:, r0:r1].contiguous() for b in bufs)
+        img = O.render(gspec, band, q, torch.tensor([[0.0, 0.0, -1.0]]), 0, 1, 12, EPS)
+        img.pow(2).sum().backward()
+
+        class Holder(torch.nn.Module):
+            def __init__(self, tensors):
+                super().__init__()
+                self.ps = torch.nn.ParameterList([torch.nn.Parameter(x.detach().clone()) for x in tensors])
+        leaves = [p for _, p in O.spec_parameters(gspec)]
+        holder = Holder(leaves)
+        for hp, p in zip(holder.ps, leaves):
+            hp.grad = p.grad.clone()
+        all_reduce_gradients(holder)
+        if rank == 0:
+            results["frames"] = {m: f.clone() for m, f in out.items()}
+            results["grads"] = [p.grad.clone() for p in holder.ps]
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world):
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    return dict(results)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_tiles_match_single_process(world):
+    got = _run(world)
+    spec = O.scene_test2()
+    bufs = O.camera_buffers(1, W, H, PX * H, PX * W, PX * H)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -3.0]])
+    for mode, frame in got["frames"].items():
+        with torch.no_grad():
+            want = O.render(spec, bufs, q, t, mode, 1, STEPS, EPS)
+        if mode in (0, 4):
+            assert torch.equal(frame, want), f"mode {mode}: tiled frame differs from the whole frame"
+        else:
+            torch.testing.assert_close(frame, want, rtol=0, atol=1e-6)   # same global min/max after all-reduce
+    gspec = O.map_spec(O.scene_test1_closed(), lambda x: x.clone().requires_grad_(True))
+    img = O.render(gspec, bufs, q, torch.tensor([[0.0, 0.0, -1.0]]), 0, 1, 12, EPS)
+    img.pow(2).sum().backward()
+    scale = max(p.grad.abs().max().item() for _, p in O.spec_parameters(gspec))
+    for (name, p), g in zip(O.spec_parameters(gspec), got["grads"]):
+        # summation order differs (per-band partial sums); tolerance relative to the gradient scale
+        torch.testing.assert_close(g, p.grad, rtol=1e-4, atol=1e-5 * scale, msg=name)
+
+
+def test_row_band_covers_every_row_once():
+    from ray_marching_amd.distributed import row_band
+    for h in (1, 7, 22, 1080, 4320):
+        for world in (1, 2, 3, 8):
+            rows = []
+            for r in range(world):
+                a, b = row_band(h, r, world)
+                assert 0 <= a <= b <= h
+                rows += list(range(a, b))
+            assert rows == list(range(h))

@@ -1,0 +1,188 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol of
+include/rm_abi.h, argument validation returns error codes (nothing is launched), the scene
+compiler lowers the reference's scenes as documented, and the module surface mirrors the
+reference (names, buffers, parameter order)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdf_oracle as O
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rm_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ray_marching_amd import _abi
+    names = declared_functions()
+    assert len(names) >= 18
+    lib = C.CDLL(_abi.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/rm_abi.h but not exported"
+    assert set(names) == set(_abi.EXPORTED_SYMBOLS), set(names) ^ set(_abi.EXPORTED_SYMBOLS)
+    assert lib.rm_abi_version() == _abi.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "rm_abi.h")).read()
+    assert f"#define RM_ABI_VERSION {_abi.ABI_VERSION}" in header
+    assert f"#define RM_WORK_WORDS" in header and _abi.WORK_WORDS == 64 + 64 * 32
+
+
+def test_bad_arguments_return_error_codes_without_launching():
+    from ray_marching_amd import _abi
+    lib = _abi.lib
+    assert lib.rm_sdf_forward(None, None, None, 4, None) == -1
+    assert b"scene" in lib.rm_last_error()
+    bogus = _abi.RmScene(program=1, params=1, n_instr=0, n_params=0, n_derived=0, stack_floats=0, n_slots=0)
+    assert lib.rm_sdf_forward(bogus, None, None, 4, None) == -1
+    ok = _abi.RmScene(program=16, params=16, n_instr=1, n_params=1, n_derived=0, stack_floats=0, n_slots=0)
+    assert lib.rm_sdf_forward(ok, None, None, 4, None) == -1          # null buffers
+    assert lib.rm_sdf_forward(ok, None, None, 0, None) == 0           # empty input: nothing to do
+    assert lib.rm_shade_finish(None, 10, None, 1, None) == -1
+    assert lib.rm_minmax_init(None, None) == -1
+    cam = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4)
+    tet = _abi.RmTetra()
+    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 9, 1, 8, 0, 4, 0, None) == -1
+    assert b"mode" in lib.rm_last_error()
+    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 0, 1, 8, 2, 9, 0, None) == -1
+    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 1, 1, 8, 0, 4, 0, None) == -1
+    assert b"minmax" in lib.rm_last_error()
+
+
+def _validate(rows, n_params, n_derived, stack, slots):
+    from ray_marching_amd import _abi
+    prog = np.asarray(rows, dtype=np.int32).reshape(-1, 4)
+    return _abi.lib.rm_validate_program(prog.ctypes.data, prog.shape[0], n_params, n_derived, stack, slots)
+
+
+def test_program_validation():
+    A = __import__("ray_marching_amd._abi", fromlist=["x"])
+    assert _validate([[A.OP_SPHERE, 0, 0, 0]], 1, 0, 0, 0) == 0
+    assert _validate([[A.OP_SPHERE, 1, 0, 0]], 1, 0, 0, 0) == -2            # parameter out of range
+    assert _validate([[99, 0, 0, 0]], 1, 0, 0, 0) == -2                     # bad opcode
+    assert _validate([[A.OP_UNION_BEGIN, 0, 0, 0], [A.OP_SPHERE, 0, 0, 0]], 1, 0, 2, 1) == -2   # unbalanced
+    assert _validate([[A.OP_SPHERE, 0, 0, 0], [A.OP_SPHERE, 0, 0, 0]], 1, 0, 0, 0) == -2        # two values
+    good = [[A.OP_UNION_BEGIN, 0, 0, 0], [A.OP_SPHERE, 0, 0, 0], [A.OP_FOLD_MIN, 0, 0, 0],
+            [A.OP_PLANE, 0, 0, 0], [A.OP_FOLD_MIN, 0, 1, 0], [A.OP_UNION_END, 0, 0, 2]]
+    assert _validate(good, 1, 0, 2, 2) == 0
+    assert _validate(good, 1, 0, 1, 2) == -2                                # stack too small
+    assert _validate(good, 1, 0, 2, 1) == -2                                # slot out of range
+    assert _validate([[A.OP_LINE, 0, 7, 0]], 7, 6, 0, 0) == 0
+    assert _validate([[A.OP_LINE, 0, 5, 0]], 7, 6, 0, 0) == -2              # derived block overlaps raw params
+
+
+def test_compiler_lowers_reference_scenes():
+    from ray_marching_amd.compiler import compile_scene
+    from ray_marching_amd.scene import scene_registry as R
+    cs2 = compile_scene(R.make_test_scene2())
+    # parameter names of make_test_scene2
+    assert cs2.leaf_names == ["sdfs.0.radius", "sdfs.0.sdf.halfsides", "sdfs.1.sdfs.0.radius",
+                              "sdfs.1.sdfs.1.radius1", "sdfs.1.sdfs.1.radius2", "sdfs.1.sdfs.2.start",
+                              "sdfs.1.sdfs.2.end", "sdfs.1.sdfs.2.radius"]
+    assert (cs2.n_params, cs2.n_derived, cs2.n_slots) == (14, 6, 6)
+    assert cs2.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test2())]
+    cs1 = compile_scene(R.make_test_scene())
+    assert cs1.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test1())]
+    assert cs1.leaf_names[0] == "blend_k" and cs1.n_params == 36
+    csc = compile_scene(R.make_closed_test_scene())
+    assert csc.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test1_closed())] and csc.n_params == 40
+    cs5 = compile_scene(R.make_many_primitive_scene(32))
+    assert cs5.leaf_names == [n for n, _ in O.spec_parameters(O.scene_many(32))]
+    # parameter VALUES of the factories equal the oracle's (same constants / same seed)
+    for factory, spec in ((R.make_test_scene2, O.scene_test2()), (R.make_closed_test_scene, O.scene_test1_closed()),
+                          (lambda: R.make_many_primitive_scene(32), O.scene_many(32))):
+        for (n1, p1), (n2, p2) in zip(factory().named_parameters(), O.spec_parameters(spec)):
+            assert n1 == n2 and torch.equal(p1.detach(), p2), n1
+    # packing is differentiable plumbing and follows the offsets
+    scene = R.make_test_scene2()
+    cs = compile_scene(scene)
+    flat = cs.pack_params("cpu")
+    assert flat.requires_grad and flat.shape == (14,)
+    assert torch.equal(flat[cs.leaf_offsets[5]:cs.leaf_offsets[5] + 3].detach(), scene.sdfs[1].sdfs[2].start.detach())
+    with torch.no_grad():
+        a = cs.pack_params("cpu")
+        assert a is cs.pack_params("cpu")                      # cached while parameters are unchanged
+        scene.sdfs[0].radius.add_(0.5)
+        assert cs.pack_params("cpu")[0].item() == pytest.approx(0.6)
+
+
+def test_foreign_module_is_rejected_loudly():
+    from ray_marching_amd.compiler import compile_scene
+    from ray_marching_amd.scene.transformations import SDFUnion
+    with pytest.raises(TypeError, match="not a ray_marching_amd SDF node"):
+        compile_scene(SDFUnion([torch.nn.Linear(3, 1)]))
+
+
+def test_no_cpu_fallback():
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.rendering.ray_marching import SDFMarcher, SDFNormals
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    scene = make_test_scene2()
+    x = torch.zeros(4, 3)
+    for call in (lambda: scene(x), lambda: SDFMarcher(scene)(x, x, 4), lambda: SDFNormals(scene)(x)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    loop = RenderLoop(scene, px_width=8, px_height=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loop(torch.tensor([[1.0, 0, 0, 0]]), torch.zeros(1, 3))
+
+
+def test_module_surface_mirrors_reference():
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.rendering.ray_marching import PinholeCamera, tetrahedron_constants
+    from ray_marching_amd.rendering import shader as S
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    h, w = 12, 16
+    cam = PinholeCamera(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    origins, directions = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    assert torch.equal(cam.ray_positions, origins) and torch.equal(cam.ray_directions, directions)
+    g = H.gold("f2_camera.npz")
+    assert np.array_equal(cam.ray_positions.numpy(), g["ray_positions"])      # reference's own buffers
+    taps, rel, inv = tetrahedron_constants(5e-2)
+    o_taps, o_inv = O.tetra_constants(5e-2)
+    assert torch.equal(taps, o_taps) and torch.equal(inv, o_inv)
+    assert inv[0, 0].item() == pytest.approx(-12.2474, abs=1e-3)             # SURVEY A6 anchor
+    loop = RenderLoop(make_test_scene2(), px_width=w, px_height=h)
+    keys = set(loop.state_dict().keys())
+    for k in ("camera.focus", "camera.theta", "camera.ray_positions", "camera.ray_directions", "camera.pixel_frames",
+              "camera.quaternion_to_so3.pairs", "normals.offsets", "normals.relative_offsets",
+              "normals.offsets_inverse", "shader.cyclic_cmap", "scene.sdfs.1.sdfs.2.start"):
+        assert k in keys, k
+    assert S.MODES == ["lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin"]
+    cm = S.default_cyclic_cmap()
+    assert cm.shape == (4096, 3) and cm.dtype == torch.float64 and 0.23 < cm.min() < 0.25 and cm.max() <= 1.0
+
+
+def test_quaternion_helpers_match_oracle():
+    from ray_marching_amd import quaternion as Q
+    gen = torch.Generator().manual_seed(5)
+    u, v = torch.randn(64, 3, generator=gen), torch.randn(64, 3, generator=gen)
+    p, q = torch.randn(64, 4, generator=gen), torch.randn(64, 4, generator=gen)
+    assert torch.equal(Q.cross_product(u, v), O.cross(u, v))
+    assert torch.equal(Q.rotation(u, q), O.quat_rotate(u, q))
+    assert torch.equal(Q.conjugate(q), O.quat_conj(q))
+    torch.testing.assert_close(Q.multiply(p, q), O.quat_multiply(p, q), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(Q.QuaternionToSO3()(q), O.quat_to_so3(q), rtol=1e-6, atol=1e-6)
+    w = Q.to_versor(torch.tensor([[0.1, 0.2, 0.2]]))
+    assert w.shape == (1, 4) and w.norm().item() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_specialisation_codegen_is_deterministic():
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compile_scene
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    a, b = compile_scene(make_test_scene2()), compile_scene(make_test_scene2())
+    assert specialize.scene_hash(a) == specialize.scene_hash(b)
+    hdr = specialize.code_header(a)
+    assert "static constexpr int n = 14" in hdr and hdr.count("{") == 16
+    assert specialize.static_backward(a)
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
+    assert not specialize.static_backward(compile_scene(make_many_primitive_scene(32)))
