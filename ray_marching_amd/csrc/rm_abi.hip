@@ -98,11 +98,17 @@ int launched(const char* what) {
   return RM_OK;
 }
 
-int reduce_partials(const RmScene& sc, const float* partials, int nblocks, float* grad_params, hipStream_t s) {
+// partials holds kMaxBlocksBwd rows of per-block sums followed by one row of totals
+int reduce_partials(const RmScene& sc, float* partials, int nblocks, float* grad_params, hipStream_t s) {
   if (!grad_params) return RM_OK;
-  size_t lds = 4 * (size_t)(sc.n_params + sc.n_derived + 1);
-  rm::k_reduce_partials<<<1, 256, lds, s>>>(sc, partials, nblocks, grad_params);
-  return launched("k_reduce_partials");
+  const int n_acc = sc.n_params + sc.n_derived;
+  if (n_acc == 0) return RM_OK;
+  float* sums = partials + (size_t)kMaxBlocksBwd * n_acc;
+  rm::k_reduce_partials<<<n_acc, 256, 0, s>>>(partials, nblocks, n_acc, sums);
+  if (int e = launched("k_reduce_partials")) return e;
+  size_t lds = 4 * (size_t)(n_acc + 1);
+  rm::k_finish_grads<<<1, 256, lds, s>>>(sc, sums, grad_params);
+  return launched("k_finish_grads");
 }
 
 }  // namespace
@@ -116,7 +122,7 @@ const char* rm_last_error(void) { return g_err; }
 int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
   if (!scene) return 0;
   (void)n;
-  return (int64_t)kMaxBlocksBwd * (scene->n_params + scene->n_derived);
+  return (int64_t)(kMaxBlocksBwd + 1) * (scene->n_params + scene->n_derived);
 }
 
 int rm_sdf_forward(const RmScene* scene, const float* points, float* dist, int64_t n, void* stream) {

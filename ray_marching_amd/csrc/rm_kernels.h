@@ -784,18 +784,29 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }
 
-// Sum the per-block partials in block order (deterministic), then push the
-// gradients of the derived capsule constants back onto start/end
-// (AB = end - start, ABs = AB / |AB|^2; primitives.py:52-54).
-__global__ void k_reduce_partials(RmScene sc, const float* __restrict__ partials, int nblocks,
-                                  float* __restrict__ grad_params) {
+// Gradient reduction, deterministic (fixed summation tree, no float atomics).
+// Stage 1: one block per accumulator; thread t sums rows t, t+256, ... then a fixed LDS tree.
+__global__ void k_reduce_partials(const float* __restrict__ partials, int nblocks, int n_acc,
+                                  float* __restrict__ sums) {
+  __shared__ float red[256];
+  const int i = blockIdx.x;
+  float acc = 0.0f;
+  for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[(int64_t)b * n_acc + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[i] = red[0];
+}
+
+// Stage 2: push the gradients of the derived capsule constants back onto start/end
+// (AB = end - start, ABs = AB / |AB|^2; primitives.py:52-54) and emit the raw-parameter vector.
+__global__ void k_finish_grads(RmScene sc, const float* __restrict__ sums, float* __restrict__ grad_params) {
   extern __shared__ float s_acc[];
   const int n_acc = sc.n_params + sc.n_derived;
-  for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
-    float sum = 0.0f;
-    for (int b = 0; b < nblocks; ++b) sum += partials[(int64_t)b * n_acc + i];
-    s_acc[i] = sum;
-  }
+  for (int i = threadIdx.x; i < n_acc; i += blockDim.x) s_acc[i] = sums[i];
   __syncthreads();
   if (threadIdx.x == 0) {
     const int4* prog = reinterpret_cast<const int4*>(sc.program);
