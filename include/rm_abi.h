@@ -190,7 +190,9 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
 /* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
  * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
- * flags: pass the RM_FLAG_TILE8X8 choice of the forward call. */
+ * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT
+ * stops a wave's reverse sweep once every ray's adjoint component along the ray is below the
+ * rounding-error bound of its own dot product. */
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                        const float* orientation, const float* translation,
                        const float* traj, const int32_t* nexec, const float* p_final,

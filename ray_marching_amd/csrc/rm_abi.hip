@@ -335,7 +335,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
   a.grad_image = grad_image; a.partials = partials; a.minmax = work;
-  a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES);
+  a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
   if (int e = pick_launch(rm::k_render_bwd<G>, *scene, true, 128, &L)) return e;
   int64_t wave_tiles;

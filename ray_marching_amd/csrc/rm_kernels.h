@@ -258,12 +258,23 @@ __global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const float* __re
 
 // Reverse sweep of the march: lambda_i = lambda_{i+1} + (lambda_{i+1}.v) grad_p f(p_i),
 // dL/dtheta += (lambda_{i+1}.v) df/dtheta(p_i), dL/dv += f(p_i) lambda_{i+1}.
+//
+// Early exit (`early`): every contribution of step i is proportional to g_i = lambda_{i+1}.v, and
+// g shrinks by (1 + grad f . v) per step through the converged tail of the trajectory (0 for a
+// head-on hit).  Once |g| is below the rounding-error bound of its own dot product,
+// 4 eps (|l_x v_x| + |l_y v_y| + |l_z v_z|), it carries no information; the wave stops when that
+// holds for all 64 rays.  The reference keeps adding such noise terms; the difference is far
+// inside the 1e-4 gradient tolerance (tests: worst |grad error| unchanged at 1e-6 level).
 template <class SceneT>
 RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
-                        int64_t ray, int nexec, int steps, V3* gv) {
+                        int64_t ray, int nexec, int steps, V3* gv, bool early) {
   for (int i = steps - 1; i >= 0; --i) {
-    V3 p = (i < nexec) ? load3(traj + 3 * (int64_t)i * traj_stride, ray) : p_final;
     float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+    if (early && !gv) {
+      float bound = 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
+      if (__all(fabsf(gf) <= bound)) break;
+    }
+    V3 p = (i < nexec) ? load3(traj + 3 * (int64_t)i * traj_stride, ray) : p_final;
     if (gv) {
       float f = scene.eval(p);
       *gv = *gv + f * lam;
@@ -294,7 +305,7 @@ __global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __re
     // so every iterate from nexec-1 on equals the last stored one.
     int ne = nexec ? nexec[ic] : steps;
     V3 pf = (ne > 0) ? load3(traj + 3 * (int64_t)(ne - 1) * n, ic) : mk3(0.0f, 0.0f, 0.0f);
-    lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs ? &gv : nullptr);
+    lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs ? &gv : nullptr, false);
     if (live) {
       if (gpos) store3(gpos, i, lam);
       if (gdirs) store3(gdirs, i, gv);
@@ -779,7 +790,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     }
     V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
     int ne = a.nexec ? a.nexec[li] : a.steps;
-    march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, nullptr);
+    march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, nullptr, a.flags & RM_FLAG_EARLY_OUT);
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }
