@@ -17,6 +17,8 @@ Fixture families:
   f4_scene2_*.npz   make_test_scene2 frames: p, dist, normals, laplacian, 8 shader modes
   f5_backward.npz   closed make_test_scene, 64x64 S=64: parameter grads (fp32 and fp64)
   f6_ties.npz       subgradient choices at ties
+  f7_*fp16*.npz     reference cast to float16 (config 3 numerics) + its own fp16-vs-fp32 spread
+  f8_*two_cameras   num_cameras = 2 batch
   cmap.npz          the reference's colormap data file (float64 [4096,3])
 """
 from __future__ import annotations
@@ -225,6 +227,34 @@ def gen_f6(ref):
     save("f6_ties.npz", **out)
 
 
+def gen_f7(ref):
+    """Config-3 style fp16 frame: the reference module cast with .to(float16) (every ATen op rounds
+    to fp16).  Also records the reference's own fp16-vs-fp32 spread, which sets the tolerance."""
+    h, w, steps = 90, 160, 32
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -3.0]])
+    img16, aux16 = frame(ref, O.scene_test2(), h, w, q, t, steps, [0, 4], dtype=torch.float16)
+    img32, aux32 = frame(ref, O.scene_test2(), h, w, q, t, steps, [0, 4], dtype=torch.float32)
+    save("f7_scene2_fp16_90x160_s32.npz", hw=np.array([h, w]), steps=np.array(steps), q=npy(q), t=npy(t),
+         eps=np.array(EPS), p16=npy(aux16["p"].float()), n16=npy(aux16["n"].float()),
+         mode0_16=npy(img16[0][..., :1].float()), mode4_16=npy(img16[4].float()),
+         mode0_32=npy(img32[0][..., :1]), mode4_32=npy(img32[4]), p32=npy(aux32["p"]),
+         ref_spread_p=np.array((aux16["p"].float() - aux32["p"]).abs().max().item()),
+         ref_spread_mode4=np.array((img16[4].float() - img32[4]).abs().max().item()),
+         ref_spread_mode0=np.array((img16[0].float() - img32[0]).abs().max().item()))
+
+
+def gen_f8(ref):
+    """Two cameras in one batch (num_cameras = 2): the reference renders [2,H,W,3]."""
+    h, w, steps = 40, 56, 48
+    q = torch.cat([torch.tensor([[1.0, 0.0, 0.0, 0.0]]),
+                   torch.nn.functional.normalize(torch.tensor([[0.95, 0.05, 0.25, -0.1]]), dim=-1)])
+    t = torch.tensor([[0.0, 0.0, -3.0], [0.4, -0.3, -3.0]])
+    images, aux = frame(ref, O.scene_test2(), h, w, q, t, steps, [0, 1, 4])
+    save("f8_scene2_two_cameras.npz", hw=np.array([h, w]), steps=np.array(steps), q=npy(q), t=npy(t),
+         eps=np.array(EPS), p=npy(aux["p"]), n=npy(aux["n"]), mode0=npy(images[0][..., :1]),
+         mode1=npy(images[1][..., :1]), mode4=npy(images[4]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -235,6 +265,8 @@ def main():
     gen_f4(ref)
     gen_f5(ref)
     gen_f6(ref)
+    gen_f7(ref)
+    gen_f8(ref)
     save("cmap.npz", cyclic_cmap=npy(ref.shader.cyclic_cmap))
 
 
