@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 5
+#define RM_ABI_VERSION 6
 
 enum {
   RM_OK = 0,
@@ -192,13 +192,24 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
  * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT
  * stops a wave's reverse sweep once every ray's adjoint component along the ray is below the
- * rounding-error bound of its own dot product. */
+ * rounding-error bound of its own dot product.
+ * grad_pos / grad_dirs: when given, the per-ray gradients w.r.t. the world-frame ray origin and
+ * direction are written (input of rm_camera_backward). */
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                        const float* orientation, const float* translation,
                        const float* traj, const int32_t* nexec, const float* p_final,
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
+                       float* grad_pos /*nullable [R,3]*/, float* grad_dirs /*nullable [R,3]*/,
                        int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags,
                        void* stream);
+
+/* VJP of PinholeCamera.forward (rendering/ray_marching.py:57-64) w.r.t. the pose: reduces per-ray
+ * gradients grad_pos / grad_dirs ([N,rows,W,3], either may be NULL) to grad_orientation [N,4] and
+ * grad_translation [N,3] (either may be NULL).  partials: N * RM_CAMERA_BWD_BLOCKS * 7 floats. */
+#define RM_CAMERA_BWD_BLOCKS 256
+int rm_camera_backward(const RmCamera* cam, const float* orientation, const float* grad_pos, const float* grad_dirs,
+                       float* grad_orientation, float* grad_translation, float* partials, int32_t row_begin,
+                       int32_t row_end, void* stream);
 
 /* Host-side check of a compiled program BEFORE it is uploaded (host pointer):
  * opcode range, parameter/slot/derived offsets inside their blocks, balanced

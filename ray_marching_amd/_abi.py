@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
 
@@ -21,6 +21,7 @@ OP_ROUND, OP_ONION = 15, 16
 
 FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES = 1, 2, 4
 WORK_WORDS = 64 + 64 * 32   # RM_WORK_WORDS
+CAMERA_BWD_BLOCKS = 256     # RM_CAMERA_BWD_BLOCKS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 
 
@@ -66,8 +67,9 @@ _SIGNATURES = {
     "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
-                                     _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "rm_camera_backward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -318,9 +318,26 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
   return launched("k_shade_fwd");
 }
 
+int rm_camera_backward(const RmCamera* cam, const float* orientation, const float* grad_pos, const float* grad_dirs,
+                       float* grad_orientation, float* grad_translation, float* partials, int32_t row_begin,
+                       int32_t row_end, void* stream) {
+  if (!cam || !cam->ray_positions || !cam->ray_directions || !orientation || !partials || (!grad_pos && !grad_dirs))
+    return fail(RM_E_BADARG, "rm_camera_backward: null buffer");
+  if (cam->num_cameras <= 0 || cam->num_cameras > 1024 || row_begin < 0 || row_end > cam->height || row_begin >= row_end)
+    return fail(RM_E_BADARG, "rm_camera_backward: bad camera shape / rows");
+  const int bpc = RM_CAMERA_BWD_BLOCKS;
+  rm::k_camera_bwd<<<cam->num_cameras * bpc, 256, 0, (hipStream_t)stream>>>(*cam, orientation, grad_pos, grad_dirs, partials,
+                                                                            row_begin, row_end, bpc);
+  if (int e = launched("k_camera_bwd")) return e;
+  rm::k_camera_bwd_finish<<<cam->num_cameras, 64, 0, (hipStream_t)stream>>>(partials, bpc, cam->num_cameras,
+                                                                            grad_orientation, grad_translation);
+  return launched("k_camera_bwd_finish");
+}
+
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
-                       const float* grad_image, float* grad_params, float* partials, uint32_t* work, int32_t mode,
+                       const float* grad_image, float* grad_params, float* partials, uint32_t* work,
+                       float* grad_pos, float* grad_dirs, int32_t mode,
                        int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, void* stream) {
 #ifdef RM_NO_BACKWARD
   return fail(RM_E_BADARG, "rm_render_backward: this specialised library was built forward-only");
@@ -335,6 +352,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
   a.grad_image = grad_image; a.partials = partials; a.minmax = work;
+  a.grad_pos = grad_pos; a.grad_dirs = grad_dirs;
   a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
   if (int e = pick_launch(rm::k_render_bwd<G>, *scene, true, 128, &L)) return e;

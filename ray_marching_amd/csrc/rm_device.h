@@ -469,10 +469,12 @@ struct Scene {
     return s.d;
   }
   // VJP at point p with upstream g: returns dL/dp, adds parameter grads into the accumulators.
-  RM_DEV V3 vjp(V3 p, float g) const {
+  // `value` (optional) receives f(p) from the recording forward pass.
+  RM_DEV V3 vjp(V3 p, float g, float* value = nullptr) const {
     Fwd<Store> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
     prog.forward(f, P);
+    if (value) *value = f.d;
     Bwd<Store> b;
     b.p = p; b.gp = mk3(0.0f, 0.0f, 0.0f); b.g = g; b.gframe = 0.0f; b.fval = 0.0f;
     b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st;

@@ -270,16 +270,25 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
                         int64_t ray, int nexec, int steps, V3* gv, bool early) {
   for (int i = steps - 1; i >= 0; --i) {
     float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
-    if (early && !gv) {
+    if (early) {
       float bound = 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
-      if (__all(fabsf(gf) <= bound)) break;
+      if (__all(fabsf(gf) <= bound)) {
+        if (gv) {
+          // steps 0..i are skipped with lambda frozen: sum_i f(p_i) = (p_{i+1} - p_0).v / |v|^2
+          V3 pn = (i + 1 < nexec) ? load3(traj + 3 * (int64_t)(i + 1) * traj_stride, ray) : p_final;
+          V3 p0 = load3(traj, ray);
+          V3 dp = pn - p0;
+          float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
+          *gv = *gv + sumf * lam;
+        }
+        break;
+      }
     }
     V3 p = (i < nexec) ? load3(traj + 3 * (int64_t)i * traj_stride, ray) : p_final;
-    if (gv) {
-      float f = scene.eval(p);
-      *gv = *gv + f * lam;
-    }
-    lam = lam + scene.vjp(p, gf);
+    float f;
+    V3 gp = scene.vjp(p, gf, &f);
+    if (gv) *gv = *gv + f * lam;
+    lam = lam + gp;
   }
   return lam;
 }
@@ -415,6 +424,8 @@ struct RenderArgs {
   // backward only
   const float* grad_image;
   float* partials;
+  float* grad_pos;           // nullable [R,3]: dL/d(ray origin)   (feeds rm_camera_backward)
+  float* grad_dirs;          // nullable [R,3]: dL/d(ray direction)
 };
 
 // Work decomposition of a frame: a *wave tile* is 64 rays handled by one wavefront --
@@ -753,6 +764,57 @@ __global__ void k_camera_fwd(RmCamera cam, const float* __restrict__ orientation
   }
 }
 
+// VJP of PinholeCamera.forward w.r.t. the pose.  pos = rot(o_c, q) + t, dir = rot(v_c, q) with
+// rot(V, q) = V + w T + u x T, T = 2 u x V.  Per ray: g_t = g_pos; g_w = g.T; g_T = w g + g x u;
+// g_u = T x g + 2 V x g_T (summed over the origin and direction terms).  Rays of rows
+// [row_begin,row_end); block partial sums [camera][block][7] in a fixed order (deterministic).
+__global__ void k_camera_bwd(RmCamera cam, const float* __restrict__ orientation, const float* __restrict__ gpos,
+                             const float* __restrict__ gdirs, float* __restrict__ partials, int row_begin,
+                             int row_end, int blocks_per_cam) {
+  __shared__ float red[7][256];
+  const int c = blockIdx.x / blocks_per_cam, b = blockIdx.x % blocks_per_cam;
+  const int W = cam.width, rows = row_end - row_begin;
+  const int64_t per_cam = (int64_t)rows * W;
+  float w = orientation[4 * c];
+  V3 u = mk3(orientation[4 * c + 1], orientation[4 * c + 2], orientation[4 * c + 3]);
+  float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int64_t r = (int64_t)b * blockDim.x + threadIdx.x; r < per_cam; r += (int64_t)blocks_per_cam * blockDim.x) {
+    int row = (int)(r / W), col = (int)(r - (int64_t)row * W);
+    int64_t li = (int64_t)c * per_cam + r;
+    int64_t gi = ((int64_t)c * cam.height + (row + row_begin)) * W + col;
+    for (int k = 0; k < 2; ++k) {
+      const float* gsrc = k ? gdirs : gpos;
+      if (!gsrc) continue;
+      V3 g = load3(gsrc, li);
+      V3 V = load3(k ? cam.ray_directions : cam.ray_positions, gi);
+      V3 T = 2.0f * cross(u, V);
+      V3 gT = w * g + cross(g, u);
+      V3 gu = cross(T, g) + 2.0f * cross(V, gT);
+      acc[0] += (g.x * T.x + g.y * T.y) + g.z * T.z;
+      acc[1] += gu.x; acc[2] += gu.y; acc[3] += gu.z;
+      if (k == 0) { acc[4] += g.x; acc[5] += g.y; acc[6] += g.z; }
+    }
+  }
+  for (int k = 0; k < 7; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2)
+      for (int k = 0; k < 7; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x < 7) partials[((int64_t)c * blocks_per_cam + b) * 7 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void k_camera_bwd_finish(const float* __restrict__ partials, int blocks_per_cam, int num_cameras,
+                                    float* __restrict__ gq, float* __restrict__ gt) {
+  int c = blockIdx.x, k = threadIdx.x;
+  if (c >= num_cameras || k >= 7) return;
+  float s = 0.0f;
+  for (int b = 0; b < blocks_per_cam; ++b) s += partials[((int64_t)c * blocks_per_cam + b) * 7 + k];
+  if (k < 4) { if (gq) gq[4 * c + k] = s; }
+  else if (gt) gt[3 * c + (k - 4)] = s;
+}
+
 // VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
 template <class Cfg>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
@@ -779,10 +841,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     V3 n; float lap;
     normals_forward(scene, T, p, c0, n, lap);
     V3 gn;
+    V3 gv = mk3(0.0f, 0.0f, 0.0f);
     if (a.mode == RM_MODE_LAMBERTIAN) {
       float c = -dot_seq(v, n);
       float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
       gn = mk3(-g * v.x, -g * v.y, -g * v.z);
+      gv = mk3(-g * n.x, -g * n.y, -g * n.z);                                    // direct dependence of the shader on v
     } else {  // RM_MODE_NORMAL
       gn = mk3((fabsf(n.x) <= 1.0f) ? gi3.x * sgn0(n.x) : 0.0f,
                (fabsf(n.y) <= 1.0f) ? gi3.y * sgn0(n.y) : 0.0f,
@@ -790,7 +854,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     }
     V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
     int ne = a.nexec ? a.nexec[li] : a.steps;
-    march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, nullptr, a.flags & RM_FLAG_EARLY_OUT);
+    lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs ? &gv : nullptr,
+                        a.flags & RM_FLAG_EARLY_OUT);
+    if (live && a.grad_pos) store3(a.grad_pos, li, lam);
+    if (live && a.grad_dirs) store3(a.grad_dirs, li, gv);
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }

@@ -201,23 +201,61 @@ def camera_struct(ray_positions, ray_directions):
                          num_cameras=n, height=h, width=w)
 
 
-def camera_forward(ray_positions, ray_directions, orientation, translation):
-    _require_device(ray_positions, "camera buffers")
-    _require_device(orientation, "orientation")
-    dev = ray_positions.device
-    rp, rd = _f32c(ray_positions), _f32c(ray_directions)
-    q, t = _f32c(orientation), _f32c(translation)
+def _camera_backward(rp, rd, q, gpos, gdirs, rows, need_q=True, need_t=True):
+    """grad_orientation [N,4], grad_translation [N,3] from per-ray gradients (rm_camera_backward)."""
+    dev = rp.device
     n = rp.shape[0]
-    if q.shape != (n, 4) or t.shape != (n, 3):
-        raise ValueError(f"camera pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
-    pos, dirs = torch.empty_like(rp), torch.empty_like(rd)
-    frames = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+    gq = torch.empty((n, 4), dtype=torch.float32, device=dev) if need_q else None
+    gt = torch.empty((n, 3), dtype=torch.float32, device=dev) if need_t else None
+    part = torch.empty(n * _abi.CAMERA_BWD_BLOCKS * 7, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         cam = camera_struct(rp, rd)
-        _abi.check(_lib.rm_camera_forward(cam, _abi.ptr(q), _abi.ptr(t), _abi.ptr(pos), _abi.ptr(dirs),
-                                          _abi.ptr(frames), _abi.current_stream(dev)), "rm_camera_forward")
-    dt = ray_positions.dtype
-    return pos.to(dt), frames.to(dt), dirs.to(dt)
+        _abi.check(_lib.rm_camera_backward(cam, _abi.ptr(q), _abi.ptr(gpos), _abi.ptr(gdirs), _abi.ptr(gq), _abi.ptr(gt),
+                                           _abi.ptr(part), rows[0], rows[1], _abi.current_stream(dev)),
+                   "rm_camera_backward")
+    return gq, gt
+
+
+class Camera(torch.autograd.Function):
+    """PinholeCamera.forward: world-frame ray origins / directions + the [N,3,3] rotation matrices."""
+
+    @staticmethod
+    def forward(ctx, orientation, translation, ray_positions, ray_directions):
+        _require_device(ray_positions, "camera buffers")
+        _require_device(orientation, "orientation")
+        dev = ray_positions.device
+        rp, rd = _f32c(ray_positions), _f32c(ray_directions)
+        q, t = _f32c(orientation), _f32c(translation)
+        n = rp.shape[0]
+        if q.shape != (n, 4) or t.shape != (n, 3):
+            raise ValueError(f"camera pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
+        pos, dirs = torch.empty_like(rp), torch.empty_like(rd)
+        frames = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            cam = camera_struct(rp, rd)
+            _abi.check(_lib.rm_camera_forward(cam, _abi.ptr(q), _abi.ptr(t), _abi.ptr(pos), _abi.ptr(dirs),
+                                              _abi.ptr(frames), _abi.current_stream(dev)), "rm_camera_forward")
+        ctx.save_for_backward(rp, rd, q)
+        ctx.mark_non_differentiable(frames)
+        dt = ray_positions.dtype
+        ctx.dt = orientation.dtype
+        return pos.to(dt), frames.to(dt), dirs.to(dt)
+
+    @staticmethod
+    def backward(ctx, gpos, gframes, gdirs):
+        rp, rd, q = ctx.saved_tensors
+        gp = _f32c(gpos) if gpos is not None else None
+        gd = _f32c(gdirs) if gdirs is not None else None
+        if gp is None and gd is None:
+            return None, None, None, None
+        gq, gt = _camera_backward(rp, rd, q, gp, gd, (0, rp.shape[1]), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if gt is not None and gp is None:
+            gt = torch.zeros_like(gt)
+        return (gq.to(ctx.dt) if gq is not None else None, gt.to(ctx.dt) if gt is not None else None, None, None)
+
+
+def camera_forward(ray_positions, ray_directions, orientation, translation):
+    return Camera.apply(orientation, translation, ray_positions, ray_directions)
 
 
 # --------------------------------------------------------------------------
@@ -246,10 +284,7 @@ class Render(torch.autograd.Function):
         r0, r1 = rows if rows is not None else (0, h)
         nrows = r1 - r0
         R = n * nrows * w
-        need_grad = ctx.needs_input_grad[0]
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError("gradients w.r.t. the camera pose are not implemented in the fused frame "
-                                      "(SURVEY 8 f2); detach orientations/translations")
+        need_grad = any(ctx.needs_input_grad[:3])
         if need_grad and mode not in (0, 4):
             raise NotImplementedError(f"fused backward exists for shader modes 0 (lambertian) and 4 (normal), not {mode}")
         image = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
@@ -292,8 +327,16 @@ class Render(torch.autograd.Function):
             work = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)
             stream = _abi.current_stream(dev)
             _abi.check(_lib.rm_minmax_init(_abi.ptr(work), stream), "rm_minmax_init")
+            need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            gpos = torch.empty_like(p_final) if need_pose else None
+            gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
             _ck(cs, cs.lib(True).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
-                                               _abi.ptr(part), _abi.ptr(work), ctx.mode, ctx.steps, ctx.rows[0],
-                                               ctx.rows[1], ctx.flags, stream), "rm_render_backward")
-        return (gprm[: prm.numel()],) + (None,) * 13
+                                               _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
+                                               ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags, stream),
+                "rm_render_backward")
+        gq = gt = None
+        if need_pose:
+            gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        gp_out = gprm[: prm.numel()] if ctx.needs_input_grad[0] else None
+        return (gp_out, gq, gt) + (None,) * 11

@@ -441,3 +441,49 @@ def test_config4_pose_optimisation():
     r = ex.run(size=128, march_steps=64, iters=150, lr=1e-3, device=DEV, log=lambda *_: None)
     print(f"config 4 optimisation: loss {r['loss_first']:.3e} -> best {min(r['losses']):.3e}")
     assert min(r["losses"]) < r["loss_first"]
+
+
+@pytest.mark.parametrize("mode", [0, 4])
+def test_camera_pose_gradients(mode, kernel_path):
+    """d loss / d (orientations, translations) through the fused frame and through the
+    stand-alone camera -> marcher -> normals chain, vs CPU autograd on the oracle."""
+    h, w, steps = 40, 48, 48
+    spec = O.scene_test1_closed()
+    bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    q0 = torch.nn.functional.normalize(torch.tensor([[0.98, 0.05, -0.12, 0.03]]), dim=-1)
+    t0 = torch.tensor([[0.15, -0.1, -1.2]])
+    gen = torch.Generator().manual_seed(11)
+    wimg = torch.rand(1, h, w, 3, generator=gen)
+    qc, tc = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    (O.render(spec, bufs, qc, tc, mode, 1, steps, H.EPS) * wimg).mean().backward()
+    # fused frame
+    module = H.spec_to_module(spec)
+    loop = H.make_loop(module, h, w)
+    _check_path(module, kernel_path)
+    qg, tg = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+    (loop(qg, tg, mode, 1, steps) * wimg.to(DEV)).mean().backward()
+    for name, got, want in (("orientation", qg.grad, qc.grad), ("translation", tg.grad, tc.grad)):
+        scale = max(1e-3, want.abs().max().item())
+        err = (got.cpu() - want).abs().max().item()
+        print(f"fused mode {mode} grad {name}: |err|={err:.2e} (scale {scale:.2e})")
+        assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, (name, err, scale)
+    # parameter grads are still right when the pose also requires grad
+    spec_g = O.map_spec(spec, lambda x: x.clone().requires_grad_(True))
+    (O.render(spec_g, bufs, q0, t0, mode, 1, steps, H.EPS) * wimg).mean().backward()
+    for (pname, want), (_, got) in zip(O.spec_parameters(spec_g), module.named_parameters()):
+        assert (got.grad.cpu() - want.grad).abs().max().item() <= 1e-4, pname
+    # stand-alone chain: camera -> marcher -> normals -> (torch) lambert-like reduction
+    q2, t2 = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+    pos, frames, _, dirs = loop.camera(q2, t2)
+    p = loop.marcher(pos, dirs, steps)
+    n, lap = loop.normals(p)
+    ((n * dirs).sum(-1, keepdim=True) * wimg.to(DEV)[..., :1]).mean().backward()
+    q3, t3 = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    pos_c, _, dirs_c = O.camera_forward(*bufs, q3, t3)
+    p_c = O.march(spec, pos_c, dirs_c, steps)
+    n_c, _ = O.normals(spec, p_c, H.EPS)
+    ((n_c * dirs_c).sum(-1, keepdim=True) * wimg[..., :1]).mean().backward()
+    for name, got, want in (("orientation", q2.grad, q3.grad), ("translation", t2.grad, t3.grad)):
+        scale = max(1e-3, want.abs().max().item())
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, ("chain", name, err, scale)
