@@ -12,6 +12,7 @@
 #endif
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -91,6 +92,16 @@ int grid_for(int64_t tiles, int cap) {
   if (tiles < 1) tiles = 1;
   return (int)(tiles < cap ? tiles : cap);
 }
+
+// tuning knobs (environment, read once): RM_BLOCK = threads per block of the frame kernels,
+// RM_MAX_BLOCKS = persistent-grid cap (0 = one block per 'blockDim/64' wave tiles, i.e. no
+// persistent loop: the hardware workgroup dispatcher hands out the tiles).
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
+int tune_max_blocks() { static int v = env_int("RM_MAX_BLOCKS", kMaxBlocks); return v; }
 
 int launched(const char* what) {
   hipError_t e = hipGetLastError();
@@ -255,7 +266,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   a.cmap = cmap; a.cmap_size = cmap_size;
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
   Launch L;
-  if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, 256, &L)) return e;
+  if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
   int64_t wave_tiles;
   {
     const int W = cam->width, rows = row_end - row_begin;
@@ -263,7 +274,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
                                            : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
-  int grid = grid_for(tiles, kMaxBlocks);
+  int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   return launched("k_render_fwd");
 }

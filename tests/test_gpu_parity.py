@@ -487,3 +487,52 @@ def test_camera_pose_gradients(mode, kernel_path):
         scale = max(1e-3, want.abs().max().item())
         err = (got.cpu() - want).abs().max().item()
         assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, ("chain", name, err, scale)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 5), (1, 9, 7), (3, 10, 13), (2, 8, 8), (1, 17, 130)])
+@pytest.mark.parametrize("tile8", [True, False])
+def test_ragged_frames_vs_oracle(shape, tile8, kernel_path):
+    """Frame sizes that are not multiples of the 8x8 wave tile / 64-ray wave, several cameras, both
+    wave->pixel mappings, whole frame and an odd row band; steps = 0 and steps = 37."""
+    n, h, w = shape
+    spec = O.scene_test2()
+    loop = H.make_loop(H.spec_to_module(spec), h, w, n=n, tile8x8=tile8)
+    _check_path(loop.scene, kernel_path)
+    gen = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    q = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0, 0.0]]) + 0.1 * torch.randn(n, 4, generator=gen), dim=-1)
+    t = torch.tensor([[0.0, 0.0, -3.0]]) + 0.2 * torch.randn(n, 3, generator=gen)
+    bufs = O.camera_buffers(n, w, h, H.PX * h, H.PX * w, H.PX * h)
+    for steps in (0, 37):
+        for mode in (4, 0):
+            with torch.no_grad():
+                want = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
+                got = loop(q.to(DEV), t.to(DEV), mode, 1, steps)
+            assert got.shape == (n, h, w, 3)
+            assert H.report(f"{shape} S={steps} mode {mode}", got, want)[0] == 0.0
+            if h >= 3:
+                band = loop(q.to(DEV), t.to(DEV), mode, 1, steps, rows=(1, h - 1))
+                assert torch.equal(band, got[:, 1:h - 1])
+    # one globally normalised mode: min/max over ALL cameras (shader.py:35-36)
+    if n * h * w > 1:
+        with torch.no_grad():
+            want = O.render(spec, bufs, q, t, 1, 1, 24, H.EPS)
+            got = loop(q.to(DEV), t.to(DEV), 1, 1, 24)
+        mx, frac = H.report(f"{shape} distance", got, want)
+        assert mx <= 1e-3 and torch.nan_to_num(got.cpu().double()).pow(2.33).sub(torch.nan_to_num(want.double()).pow(2.33)).abs().max() <= TOL
+
+
+def test_bad_calls_raise():
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), 8, 8)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.zeros(1, 3, device=DEV)
+    from ray_marching_amd._abi import RmError
+    with pytest.raises(RmError):
+        loop(q, t, 0, 1, 8, rows=(4, 4))          # empty band
+    with pytest.raises(RmError):
+        loop(q, t, 0, 1, 8, rows=(0, 9))          # band outside the frame
+    with pytest.raises(RmError):
+        loop(q, t, 0, 1, -1)                      # negative step count
+    with pytest.raises(NotImplementedError):
+        loop.scene.sdfs[0].radius.requires_grad_(True)
+        loop(q, t, 1, 1, 8).sum().backward()      # no fused VJP for the distance shader
+    with pytest.raises(NotImplementedError):
+        loop.shader(None, q, None, None, None, None, None, None, mode="lambertian", degree=1)
