@@ -101,7 +101,9 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
-int tune_max_blocks() { static int v = env_int("RM_MAX_BLOCKS", kMaxBlocks); return v; }
+// frame kernel: 1280 blocks x 4 waves = 5 waves/SIMD measured best with the atomic tile queues
+// (profiles/grid_sweep.py: 512 -> 463 us, 1024 -> 376, 1280 -> 371, 2048 -> 390)
+int tune_max_blocks() { static int v = env_int("RM_MAX_BLOCKS", 1280); return v; }
 
 int launched(const char* what) {
   hipError_t e = hipGetLastError();

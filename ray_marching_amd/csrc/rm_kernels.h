@@ -473,26 +473,38 @@ RM_DEV uint32_t queue_size(int64_t ntiles, int q) {
   return (q < ntiles) ? (uint32_t)((ntiles - q + RM_WORK_QUEUES - 1) / RM_WORK_QUEUES) : 0u;
 }
 
+// Every wave's FIRST tile is static: wave w takes position w/64 of its home queue w%64, so the
+// counters logically start at `first_positions(q)` (the number of waves whose home is q) and the
+// burst of one atomic per wave at kernel start -- the most contended moment -- never happens.
+RM_DEV uint32_t first_positions(int q) {
+  const int total_waves = gridDim.x * (blockDim.x >> 6);
+  return (q < total_waves) ? (uint32_t)((total_waves - q + RM_WORK_QUEUES - 1) / RM_WORK_QUEUES) : 0u;
+}
+
 RM_DEV int64_t grab_wave_tile(uint32_t* work, int64_t ntiles, int& q) {
   const int lane = threadIdx.x & 63;
   uint32_t* ctr = work + RM_WORK_QUEUE_BASE;
   for (int attempt = 0; attempt < 4 * RM_WORK_QUEUES; ++attempt) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&ctr[q * RM_WORK_QUEUE_STRIDE], 1u);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + first_positions(q);
     if (t < queue_size(ntiles, q)) return (int64_t)q + (int64_t)t * RM_WORK_QUEUES;
     // home queue is empty: look at all of them at once
     uint32_t c = __hip_atomic_load(&ctr[lane * RM_WORK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = __ballot(c < queue_size(ntiles, lane));
+    unsigned long long avail = __ballot(c + first_positions(lane) < queue_size(ntiles, lane));
     if (avail == 0ull) return -1;
-    unsigned long long rot = (q == 63) ? avail : ((avail >> (q + 1)) | (avail << (63 - q)));
-    q = (q + 1 + __builtin_ctzll(rot)) & 63;
+    // steal from the first non-empty queue after a per-wave pseudo-random start (if every wave of an
+    // emptied queue moved to the SAME neighbour they would travel round the ring as a convoy)
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int r = (int)(((wave * 2654435761u) >> 20) + attempt * 17) & 63;
+    unsigned long long rot = (r == 0) ? avail : ((avail >> r) | (avail << (64 - r)));
+    q = (r + __builtin_ctzll(rot)) & 63;
   }
   // not reached in practice; finish with a definitive sweep so no tile can be dropped
   for (int k = 0; k < RM_WORK_QUEUES; ++k) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&ctr[k * RM_WORK_QUEUE_STRIDE], 1u);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + first_positions(k);
     if (t < queue_size(ntiles, k)) { q = k; return (int64_t)k + (int64_t)t * RM_WORK_QUEUES; }
   }
   return -1;
@@ -508,8 +520,8 @@ RM_DEV TileCursor first_wave_tile(const RenderArgs& a, int64_t ntiles) {
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   c.q = (int)(wave & (RM_WORK_QUEUES - 1));
   if (a.minmax && (a.flags & RM_FLAG_DYNAMIC_TILES)) {
-    c.tile = grab_wave_tile(a.minmax, ntiles, c.q);
-    if (c.tile < 0) c.tile = ntiles;
+    // static first tile: position wave/64 of the home queue (tile index == wave when it exists)
+    c.tile = (wave < ntiles) ? wave : ntiles;
   } else {
     c.tile = wave;
   }
