@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--static-tiles", action="store_true", help="static tile striding instead of the atomic tile queues")
     ap.add_argument("--camera-z", type=float, default=-3.0, help="camera position (0,0,z); SURVEY 8d uses -3 and +1")
     ap.add_argument("--skip-backward", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (single-GPU box)")
     return ap.parse_args()
 
 
@@ -141,13 +143,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -193,7 +198,12 @@ def main():
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
                     img.record_stream(comm)
-                    dist.gather(img, gathered[j] if rank == 0 else None, dst=0)
+                    if args.backend == "nccl":
+                        dist.gather(img, gathered[j] if rank == 0 else None, dst=0)
+                    else:   # rehearsal backends move host tensors
+                        host = img.cpu()
+                        parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                        dist.gather(host, parts, dst=0)
             handles.append(img)
         return handles
 
