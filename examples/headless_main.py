@@ -18,6 +18,7 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--out", default=None)
     ap.add_argument("--dtype", default="float32", choices=["float32", "float16"])
+    ap.add_argument("--graph", action="store_true", help="replay each shader mode's frame from a captured HIP graph")
     a = ap.parse_args()
     device, dtype = torch.device("cuda"), getattr(torch, a.dtype)
     num_cameras, (px_width, px_height), px_size, marching_steps = 1, (1440, 900), 3.45e-6, 32   # main.py:20-26
@@ -31,5 +32,15 @@ if __name__ == "__main__":
     events.position, events.orientation = events.position.to(dtype), events.orientation.to(dtype)
     events.velocity, events.angular_velocity = events.velocity.to(dtype), events.angular_velocity.to(dtype)
     window = FrameSink(px_width, px_height, "Window", out_dir=a.out)
-    fps = run_headless(render_loop, events, window, a.frames)
+    if a.graph:
+        frames = {}
+
+        def graphed(orientations, positions, mode, degree, steps):
+            key = (mode % 8, degree, steps)
+            if key not in frames:
+                frames[key] = render_loop.capture(mode, degree, steps)
+            return frames[key](orientations, positions)
+        fps = run_headless(graphed, events, window, a.frames)
+    else:
+        fps = run_headless(render_loop, events, window, a.frames)
     print(f"{fps:.1f} frames per second ({px_width}x{px_height}, {marching_steps} steps, {a.dtype}, all 8 shader modes cycled)")

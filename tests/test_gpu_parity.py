@@ -536,3 +536,25 @@ def test_bad_calls_raise():
         loop(q, t, 1, 1, 8).sum().backward()      # no fused VJP for the distance shader
     with pytest.raises(NotImplementedError):
         loop.shader(None, q, None, None, None, None, None, None, mode="lambertian", degree=1)
+
+
+def test_captured_graph_replay_matches_eager():
+    """RenderLoop.capture(): HIP-graph replay of a frame equals the eager call, follows pose changes and
+    in-place scene-parameter edits without re-capture."""
+    h, w, steps = 90, 160, 48
+    module = H.spec_to_module(O.scene_test2())
+    loop = H.make_loop(module, h, w)
+    q = torch.nn.functional.normalize(torch.tensor([[0.95, 0.05, 0.25, -0.1]]), dim=-1).to(DEV)
+    for mode in (4, 1):
+        frame = loop.capture(mode, 1, steps)
+        for z in (-3.0, -2.0):
+            t = torch.tensor([[0.2, 0.0, z]], device=DEV)
+            with torch.no_grad():
+                want = loop(q, t, mode, 1, steps)
+            assert torch.equal(frame(q, t), want)
+        with torch.no_grad():
+            module.sdfs[1].sdfs[0].radius.add_(0.2)          # edit the sphere radius in place
+            want = loop(q, t, mode, 1, steps)
+        assert torch.equal(frame(q, t), want)
+        with torch.no_grad():
+            module.sdfs[1].sdfs[0].radius.sub_(0.2)
