@@ -200,8 +200,8 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 template <class SceneT>
 RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* traj, int64_t traj_stride,
                 int64_t ray, bool live, int& nexec) {
-  V3 snap = p;          // remembered iterate p_s
-  int snap_step = 0;    // s
+  V3 snap = p;          // remembered iterate p_s (per lane)
+  int snap_step = 0;    // s            (wave-uniform: every lane refreshes at the same steps)
   int next_snap = 1;    // refresh the snapshot when the step index reaches this (1, 2, 4, ...)
   int lambda = 0;       // cycle length of this ray, 0 = not known yet
   nexec = steps;
@@ -210,10 +210,11 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
     float f = scene.eval(p);
     V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
     if (early) {
-      if (lambda == 0) {
-        if (same_bits(pn, p)) lambda = 1;
-        else if (!traj && same_bits(pn, snap)) lambda = i + 1 - snap_step;
-      }
+      // branch-free per-lane bookkeeping (selects, no exec-mask juggling)
+      const bool fixed = same_bits(pn, p);
+      const bool cyc = !traj && same_bits(pn, snap);
+      const int found = fixed ? 1 : (cyc ? (i + 1 - snap_step) : 0);
+      lambda = (lambda == 0) ? found : lambda;
       if (__all(lambda > 0)) {
         nexec = i + 1;
         int need = (steps - (i + 1)) % lambda;    // further steps this lane still has to take
@@ -226,8 +227,8 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
         }
         return p;
       }
-      if (i + 1 == next_snap) {                   // wave-uniform: i and next_snap are scalars
-        if (lambda == 0) { snap = pn; snap_step = i + 1; }
+      if (i + 1 == next_snap) {                   // scalar condition; lanes that already know their
+        snap = pn; snap_step = i + 1;             // period no longer look at the snapshot
         next_snap <<= 1;
       }
     }
