@@ -49,6 +49,8 @@ class CompiledScene:
             return _abi.lib
         if self._lib is None:
             self._lib = specialize.load(self) or _abi.lib
+        if self._lib is _abi.lib and specialize.note_interpreted_launch(self):
+            self._lib = specialize.load(self) or _abi.lib      # a background build has finished
         return self._lib
 
     @property

@@ -216,3 +216,27 @@ def test_headless_stand_ins_follow_the_reference_contracts(tmp_path):
         sink.draw(rgba[:, :, :3])
     with pytest.raises(ValueError):
         sink.draw(rgba.double())
+
+
+def test_background_specialisation_policy(monkeypatch, tmp_path):
+    """"auto" policy: a scene that keeps running on the interpreter gets ONE background hipcc build after
+    RM_SPECIALIZE_AFTER launches and is switched over when the library exists (no GPU involved)."""
+    from ray_marching_amd import _abi, specialize
+    from ray_marching_amd.compiler import compile_scene
+    from ray_marching_amd.scene.primitives import SDFDisk
+    from ray_marching_amd.scene.transformations import SDFRounding
+    monkeypatch.setattr(specialize, "SPEC_DIR", str(tmp_path))
+    monkeypatch.setenv("RM_SPECIALIZE", "auto")
+    monkeypatch.setenv("RM_SPECIALIZE_AFTER", "3")
+    specialize._loaded.clear(); specialize._uses.clear()
+    cs = compile_scene(SDFRounding(SDFDisk(0.7), 0.05))        # a topology nobody prebuilt
+    assert cs.lib() is _abi.lib and cs.lib() is _abi.lib        # launches 1, 2: interpreter, no build
+    assert specialize._builder["thread"] is None
+    assert cs.lib() is _abi.lib                                 # launch 3 starts the background build
+    assert specialize._builder["thread"] is not None
+    specialize.wait_for_background_build(180)
+    assert os.path.isfile(specialize.lib_path(cs))
+    assert cs.lib() is not _abi.lib and cs.specialised          # picked up on the next launch
+    monkeypatch.setenv("RM_SPECIALIZE", "off")
+    assert compile_scene(SDFRounding(SDFDisk(0.7), 0.05)).lib() is _abi.lib
+    specialize._loaded.clear(); specialize._uses.clear()
