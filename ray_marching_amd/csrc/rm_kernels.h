@@ -668,57 +668,84 @@ __global__ void k_shade_fwd(ShadeArgs a) {
     fold_minmax(a.minmax, lo, hi, saw_nan);
 }
 
+// ---- per-tile pieces of the frame kernel ------------------------------------------------------------
+struct TileRays {
+  V3 o, v;          // world-frame ray of this lane
+  Pose ps;
+  int64_t li;       // index in the band outputs
+  bool live;
+};
+
+RM_DEV TileRays load_tile_rays(const RenderArgs& a, int64_t tile) {
+  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
+  TileRays r;
+  int cam, row, col;
+  r.live = ray_of_lane(a, tile, cam, row, col);
+  if (!r.live) { cam = 0; row = 0; col = 0; }
+  r.li = ((int64_t)cam * rows + row) * W + col;                          // index in the band outputs
+  int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;       // index in the camera buffers
+  r.ps = load_pose(a.orientation, a.translation, cam);
+  // PinholeCamera.forward (ray_marching.py:58-62)
+  r.o = qrot(load3(a.cam.ray_positions, gi), r.ps.w, r.ps.qv) + r.ps.t;
+  r.v = qrot(load3(a.cam.ray_directions, gi), r.ps.w, r.ps.qv);
+  return r;
+}
+
+struct MinMaxAcc {
+  float lo, hi;
+  bool saw_nan;
+};
+
+// distance, normals / Laplacian, shader, stores (control.py:244-257)
+template <class SceneT>
+RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T, const TileRays& r, V3 p, int nexec,
+                        MinMaxAcc& mm) {
+  float dist = scene.eval(p);
+  V3 n = mk3(0.0f, 0.0f, 0.0f);
+  float lap = 0.0f;
+  const int mode = a.mode;
+  if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap);
+  ShadeIn si;
+  si.o = r.o; si.v = r.v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
+  si.qw = r.ps.w; si.qv = r.ps.qv;
+  {   // third column of the camera rotation (QuaternionToSO3, quaternion.py:114-124)
+    float w = r.ps.w, x = r.ps.qv.x, y = r.ps.qv.y, z = r.ps.qv.z;
+    si.col2 = mk3(2.0f * (w * y + x * z), 2.0f * (y * z - w * x), ((w * w - x * x) - y * y) + z * z);
+  }
+  V3 out = shade_pixel(mode, si, a.cmap, a.cmap_size, a.degree);
+  if (r.live) {
+    store3(a.image, r.li, out);
+    if (a.p_final) store3(a.p_final, r.li, p);
+    if (a.nexec) a.nexec[r.li] = nexec;
+    if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
+      mm.saw_nan |= (out.x != out.x);
+      mm.lo = fminf(mm.lo, out.x); mm.hi = fmaxf(mm.hi, out.x);
+    } else if (mode == RM_MODE_LAPLACIAN) {
+      mm.saw_nan |= (lap != lap);
+      mm.hi = fmaxf(mm.hi, fabsf(lap));
+    }
+  }
+}
+
 template <class Cfg>
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store);
   Tetra T = load_tetra(a.tetra);
-  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
-  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
+  const int rows = a.row_end - a.row_begin;
+  const int64_t R = (int64_t)a.cam.num_cameras * rows * a.cam.width;
   const bool early = a.flags & RM_FLAG_EARLY_OUT;
-  float lo = __builtin_inff(), hi = -__builtin_inff();
-  bool saw_nan = false;
+  MinMaxAcc mm{__builtin_inff(), -__builtin_inff(), false};
   const int64_t ntiles = wave_tiles(a);
+
   for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
-    int cam, row, col;
-    bool live = ray_of_lane(a, tc.tile, cam, row, col);
-    if (!live) { cam = 0; row = 0; col = 0; }
-    int64_t li = ((int64_t)cam * rows + row) * W + col;                  // index in the band outputs
-    int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;     // index in the camera buffers
-    Pose ps = load_pose(a.orientation, a.translation, cam);
-    // PinholeCamera.forward (ray_marching.py:58-62)
-    V3 o = qrot(load3(a.cam.ray_positions, gi), ps.w, ps.qv) + ps.t;
-    V3 v = qrot(load3(a.cam.ray_directions, gi), ps.w, ps.qv);
+    TileRays r = load_tile_rays(a, tc.tile);
     int nexec;
-    V3 p = march(scene, o, v, a.steps, early, a.traj, R, li, live, nexec);
-    float dist = scene.eval(p);                                          // control.py:244
-    V3 n = mk3(0.0f, 0.0f, 0.0f);
-    float lap = 0.0f;
-    const int mode = a.mode;
-    if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap);
-    ShadeIn si;
-    si.o = o; si.v = v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
-    si.qw = ps.w; si.qv = ps.qv;
-    {   // third column of the camera rotation (QuaternionToSO3, quaternion.py:114-124)
-      float w = ps.w, x = ps.qv.x, y = ps.qv.y, z = ps.qv.z;
-      si.col2 = mk3(2.0f * (w * y + x * z), 2.0f * (y * z - w * x), ((w * w - x * x) - y * y) + z * z);
-    }
-    V3 out = shade_pixel(mode, si, a.cmap, a.cmap_size, a.degree);
-    if (live) {
-      store3(a.image, li, out);
-      if (a.p_final) store3(a.p_final, li, p);
-      if (a.nexec) a.nexec[li] = nexec;
-      if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
-        saw_nan |= (out.x != out.x);
-        lo = fminf(lo, out.x); hi = fmaxf(hi, out.x);
-      } else if (mode == RM_MODE_LAPLACIAN) {
-        saw_nan |= (lap != lap);
-        hi = fmaxf(hi, fabsf(lap));
-      }
-    }
+    V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec);
+    finish_tile(a, scene, T, r, p, nexec, mm);
   }
   if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
-    fold_minmax(a.minmax, lo, hi, saw_nan);
+    fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
 }
 
 // second pass for the globally normalised shaders
