@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 6
+#define RM_ABI_VERSION 7
 
 enum {
   RM_OK = 0,
@@ -186,6 +186,12 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
                      const float* coords, const float* normals, const float* lap, const float* dist, float* image,
                      uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
                      int64_t n_pixels, int64_t pixels_per_camera, void* stream);
+
+/* VJP of rm_shade_forward for the per-pixel shaders that have one: Lambertian (0), vignette (3),
+ * normal (4).  grad_image: [n_pixels, 1] (modes 0, 3) or [n_pixels, 3] (mode 4).  Outputs nullable. */
+int rm_shade_backward(const float* dirs, const float* normals, const float* frames, const float* grad_image,
+                      float* grad_dirs, float* grad_normals, int32_t mode, int64_t n_pixels,
+                      int64_t pixels_per_camera, void* stream);
 
 /* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
  * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
 
@@ -66,6 +66,7 @@ _SIGNATURES = {
     "rm_shade_finish": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P]),
     "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int64, C.c_int64, _P]),
+    "rm_shade_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

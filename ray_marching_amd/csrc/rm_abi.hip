@@ -331,6 +331,21 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
   return launched("k_shade_fwd");
 }
 
+int rm_shade_backward(const float* dirs, const float* normals, const float* frames, const float* grad_image,
+                      float* grad_dirs, float* grad_normals, int32_t mode, int64_t n_pixels,
+                      int64_t pixels_per_camera, void* stream) {
+  if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_VIGNETTE || mode == RM_MODE_NORMAL))
+    return fail(RM_E_BADARG, "rm_shade_backward: mode %d has no VJP (modes 0, 3, 4 do)", mode);
+  if (!grad_image || n_pixels < 0 || pixels_per_camera <= 0) return fail(RM_E_BADARG, "rm_shade_backward: bad args");
+  if ((mode != RM_MODE_NORMAL && !dirs) || (mode != RM_MODE_VIGNETTE && !normals) || (mode == RM_MODE_VIGNETTE && !frames))
+    return fail(RM_E_BADARG, "rm_shade_backward: an input required by mode %d is null", mode);
+  if (n_pixels == 0) return RM_OK;
+  rm::ShadeBwdArgs a{dirs, normals, frames, grad_image, grad_dirs, grad_normals, mode, n_pixels, pixels_per_camera};
+  int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
+  rm::k_shade_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return launched("k_shade_bwd");
+}
+
 int rm_camera_backward(const RmCamera* cam, const float* orientation, const float* grad_pos, const float* grad_dirs,
                        float* grad_orientation, float* grad_translation, float* partials, int32_t row_begin,
                        int32_t row_end, void* stream) {

@@ -804,6 +804,41 @@ __global__ void k_camera_fwd(RmCamera cam, const float* __restrict__ orientation
   }
 }
 
+// VJP of the per-pixel shaders that have one: Lambertian (mode 0), vignette (3), normal (4).
+// grad_image is [n, C] with C = 1 (modes 0, 3) or 3 (mode 4); outputs may be null.
+struct ShadeBwdArgs {
+  const float *dirs, *normals, *frames, *grad_image;
+  float *grad_dirs, *grad_normals;
+  int32_t mode;
+  int64_t n, per_camera;
+};
+
+__global__ void k_shade_bwd(ShadeBwdArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+    V3 gv = mk3(0.0f, 0.0f, 0.0f), gn = mk3(0.0f, 0.0f, 0.0f);
+    if (a.mode == RM_MODE_LAMBERTIAN) {        // clamp(-(v.n), 0, 1): grad passes on the closed interval
+      V3 v = load3(a.dirs, i), n = load3(a.normals, i);
+      float c = -dot_seq(v, n);
+      float g = (c >= 0.0f && c <= 1.0f) ? a.grad_image[i] : 0.0f;
+      gv = mk3(-g * n.x, -g * n.y, -g * n.z);
+      gn = mk3(-g * v.x, -g * v.y, -g * v.z);
+    } else if (a.mode == RM_MODE_VIGNETTE) {   // (v . col2)^3
+      int cam = (int)(i / a.per_camera);
+      V3 v = load3(a.dirs, i);
+      V3 c2 = mk3(a.frames[9 * cam + 2], a.frames[9 * cam + 5], a.frames[9 * cam + 8]);
+      float d = dot_seq(v, c2);
+      float g = a.grad_image[i] * (3.0f * (d * d));
+      gv = mk3(g * c2.x, g * c2.y, g * c2.z);
+    } else {                                   // clamp(|n|, 0, 1) per channel
+      V3 n = load3(a.normals, i), g = load3(a.grad_image, i);
+      gn = mk3((fabsf(n.x) <= 1.0f) ? g.x * sgn0(n.x) : 0.0f, (fabsf(n.y) <= 1.0f) ? g.y * sgn0(n.y) : 0.0f,
+               (fabsf(n.z) <= 1.0f) ? g.z * sgn0(n.z) : 0.0f);
+    }
+    if (a.grad_dirs) store3(a.grad_dirs, i, gv);
+    if (a.grad_normals) store3(a.grad_normals, i, gn);
+  }
+}
+
 // VJP of PinholeCamera.forward w.r.t. the pose.  pos = rot(o_c, q) + t, dir = rot(v_c, q) with
 // rot(V, q) = V + w T + u x T, T = 2 u x V.  Per ray: g_t = g_pos; g_w = g.T; g_T = w g + g x u;
 // g_u = T x g + 2 V x g_T (summed over the origin and direction terms).  Rays of rows

@@ -97,13 +97,61 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
 
 def _no_grad_inputs(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("stand-alone shader modules have no backward kernel; differentiate through "
-                                  "RenderLoop (modes 0 and 4) instead")
+        raise NotImplementedError("this shader has no backward kernel (the Lambertian, vignette and normal "
+                                  "shaders do); differentiate through those or through RenderLoop modes 0 / 4")
+
+
+class _PixelShade(torch.autograd.Function):
+    """Differentiable wrapper for the per-pixel shaders with a VJP kernel (modes 0, 3, 4)."""
+
+    @staticmethod
+    def forward(ctx, dirs, normals, frames, mode: int):
+        out = shade(mode, dirs=dirs, normals=normals, frames=frames)
+        ctx.mode = mode
+        ctx.save_for_backward(*(t for t in (dirs, normals, frames) if t is not None))
+        ctx.have = (dirs is not None, normals is not None, frames is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        it = iter(ctx.saved_tensors)
+        dirs, normals, frames = (next(it) if h else None for h in ctx.have)
+        ref = dirs if dirs is not None else normals
+        lead = torch.broadcast_shapes(*(t.shape[:-1] for t in (dirs, normals) if t is not None))
+        dev = ref.device
+        n = 1
+        for d in lead:
+            n *= d
+        per_cam = n // lead[0] if len(lead) > 1 else n
+        ch = 3 if ctx.mode == 4 else 1
+        g = _f32c(grad.expand(*lead, ch)).reshape(-1, ch)
+        d32 = None if dirs is None else _f32c(dirs.expand(*lead, 3)).reshape(-1, 3)
+        n32 = None if normals is None else _f32c(normals.expand(*lead, 3)).reshape(-1, 3)
+        f32 = None if frames is None else _f32c(frames).reshape(-1, 9)
+        gd = torch.empty((n, 3), dtype=torch.float32, device=dev) if (dirs is not None and ctx.needs_input_grad[0]) else None
+        gn = torch.empty((n, 3), dtype=torch.float32, device=dev) if (normals is not None and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device(dev):
+            _abi.check(_lib.rm_shade_backward(_abi.ptr(d32), _abi.ptr(n32), _abi.ptr(f32), _abi.ptr(g), _abi.ptr(gd),
+                                              _abi.ptr(gn), ctx.mode, n, per_cam, _abi.current_stream(dev)),
+                       "rm_shade_backward")
+
+        def fit(t, like):
+            if t is None:
+                return None
+            t = t.view(*lead, 3).to(like.dtype)
+            return t.sum_to_size(like.shape) if tuple(like.shape) != tuple(t.shape) else t
+
+        return fit(gd, dirs) if dirs is not None else None, fit(gn, normals) if normals is not None else None, None, None
+
+
+def _differentiable(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 class LambertianShader(nn.Module):
     def forward(self, ray_directions: Tensor, surface_normals: Tensor) -> Tensor:
-        _no_grad_inputs(ray_directions, surface_normals)
+        if _differentiable(ray_directions, surface_normals):
+            return _PixelShade.apply(ray_directions, surface_normals, None, 0)
         return shade(0, dirs=ray_directions, normals=surface_normals)
 
 
@@ -121,13 +169,15 @@ class ProximityShader(nn.Module):
 
 class VignetteShader(nn.Module):
     def forward(self, ray_directions: Tensor, pixel_frames: Tensor) -> Tensor:
-        _no_grad_inputs(ray_directions)
+        if _differentiable(ray_directions):
+            return _PixelShade.apply(ray_directions, None, pixel_frames, 3)
         return shade(3, dirs=ray_directions, frames=pixel_frames)
 
 
 class NormalShader(nn.Module):
     def forward(self, surface_normals: Tensor) -> Tensor:
-        _no_grad_inputs(surface_normals)
+        if _differentiable(surface_normals):
+            return _PixelShade.apply(None, surface_normals, None, 4)
         return shade(4, normals=surface_normals)
 
 
@@ -178,6 +228,13 @@ class Shader(nn.Module):
                 surface_distances: Tensor, mode: int, degree: int) -> Tensor:
         if not isinstance(mode, int):
             raise NotImplementedError(f"{mode=} rendering mode not implemented.")
+        m = mode % len(MODES)
+        if m == 0:
+            return self.lambertian_shader(ray_directions, surface_normals)
+        if m == 3:
+            return self.vignette_shader(ray_directions, pixel_frames)
+        if m == 4:
+            return self.normal_shader(surface_normals)
         _no_grad_inputs(px_coords, ray_directions, surface_coords, surface_normals, surface_laplacian, surface_distances)
         return shade(mode, degree, px_coords=px_coords, orientation=camera_orientation, frames=pixel_frames,
                      dirs=ray_directions, coords=surface_coords, normals=surface_normals, lap=surface_laplacian,

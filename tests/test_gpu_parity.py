@@ -558,3 +558,45 @@ def test_captured_graph_replay_matches_eager():
         assert torch.equal(frame(q, t), want)
         with torch.no_grad():
             module.sdfs[1].sdfs[0].radius.sub_(0.2)
+
+
+def test_standalone_chain_with_shader_modules_is_differentiable():
+    """camera -> marcher -> normals -> Shader(mode) composed by hand like RenderLoop.forward
+    (control.py:239-257), back-propagated to scene parameters and pose, vs CPU autograd."""
+    h, w, steps = 24, 32, 40
+    spec = O.map_spec(O.scene_test1_closed(), lambda x: x.clone().requires_grad_(True))
+    module = H.spec_to_module(spec)
+    loop = H.make_loop(module, h, w)
+    bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    q0 = torch.nn.functional.normalize(torch.tensor([[0.98, 0.05, -0.12, 0.03]]), dim=-1)
+    t0 = torch.tensor([[0.15, -0.1, -1.2]])
+    gen = torch.Generator().manual_seed(5)
+    for mode in (0, 3, 4):
+        ch = 3 if mode == 4 else 1
+        wimg = torch.rand(1, h, w, ch, generator=gen)
+        for _, p in O.spec_parameters(spec):
+            p.grad = None
+        for p in module.parameters():
+            p.grad = None
+        qc, tc = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+        (O.render(spec, bufs, qc, tc, mode, 1, steps, H.EPS)[..., :ch] * wimg).mean().backward()
+        qg, tg = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+        pos, frames, _, dirs = loop.camera(qg, tg)
+        p = loop.marcher(pos, dirs, steps)
+        dist = loop.scene(p)
+        n, lap = loop.normals(p)
+        img = loop.shader(pos, qg, frames, dirs, p, n, lap, dist, mode=mode, degree=1)
+        assert img.shape == (1, h, w, ch)
+        (img * wimg.to(DEV)).mean().backward()
+        for name, got, want in (("orientation", qg.grad, qc.grad), ("translation", tg.grad, tc.grad)):
+            if mode == 3 and name == "orientation":
+                continue      # frames (QuaternionToSO3) is not differentiated here; dirs carries the pose
+            if want is None:  # vignette does not depend on the camera translation at all
+                assert got is None or float(got.abs().max()) == 0.0
+                continue
+            scale = max(1e-3, want.abs().max().item())
+            err = (got.cpu() - want).abs().max().item()
+            assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, (mode, name, err, scale)
+        if mode != 3:
+            for (pname, want), (_, got) in zip(O.spec_parameters(spec), module.named_parameters()):
+                assert (got.grad.cpu() - want.grad).abs().max().item() <= 1e-4, (mode, pname)
