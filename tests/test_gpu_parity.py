@@ -600,3 +600,21 @@ def test_standalone_chain_with_shader_modules_is_differentiable():
         if mode != 3:
             for (pname, want), (_, got) in zip(O.spec_parameters(spec), module.named_parameters()):
                 assert (got.grad.cpu() - want.grad).abs().max().item() <= 1e-4, (mode, pname)
+
+
+@pytest.mark.parametrize("cam_z", [-3.0, 1.0])
+def test_config2_whole_frame_sample_vs_oracle(cam_z):
+    """BASELINE config 2 at full size (1920x1080, 128 steps, scene2): every 8th pixel row and column
+    of the complete frame -- walls with their sliding rays, silhouettes, the torus interior for the
+    reference's default camera (0,0,1) -- must equal the oracle bit for bit (normal + Lambertian)."""
+    h, w, steps, stride = 1080, 1920, 128, 8
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, cam_z]])
+    bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    sub = tuple(b[:, ::stride, ::stride].contiguous() for b in bufs)
+    for mode in (4, 0):
+        with torch.no_grad():
+            want = O.render(O.scene_test2(), sub, q, t, mode, 1, steps, H.EPS)
+            got = loop(q.to(DEV), t.to(DEV), mode, 1, steps)[:, ::stride, ::stride]
+        mx, _ = H.report(f"config 2 z={cam_z} mode {mode}", got, want)
+        assert mx == 0.0, (cam_z, mode, mx)
