@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--static-tiles", action="store_true", help="static tile striding instead of the atomic tile queues")
     ap.add_argument("--camera-z", type=float, default=-3.0, help="camera position (0,0,z); SURVEY 8d uses -3 and +1")
     ap.add_argument("--skip-backward", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary 2-stream pipelined measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (single-GPU box)")
     return ap.parse_args()
@@ -291,7 +292,7 @@ def main():
                                   "algorithmic_flops_per_launch": evals * FLOPS_PER_EVAL,
                                   "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer"}},
         }
-        if world == 1:
+        if world == 1 and not args.no_pipelined:
             out["pipelined"] = pipelined_probe(loop, q, t, rows, dev, rays_per_frame)
         if not args.skip_backward:
             log("backward probe (config 4 shape) ...")
