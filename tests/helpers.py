@@ -70,3 +70,48 @@ def report(name, got, want):
     err = (torch.nan_to_num(got) - torch.nan_to_num(want)).abs()
     err = torch.where(torch.isinf(got) & (got == want), torch.zeros_like(err), err)
     return float(err.max()) if err.numel() else 0.0, float((err > 1e-5).double().mean()) if err.numel() else 0.0
+
+
+def random_spec(gen, depth=0, max_depth=4):
+    """Random SDF tree over all 11 node types (oracle spec); `gen` is a torch.Generator."""
+    def u(lo, hi, n=None):
+        x = torch.rand(n or 1, generator=gen) * (hi - lo) + lo
+        return x if n else x[0]
+
+    def leaf():
+        k = int(torch.randint(0, 6, (1,), generator=gen))
+        if k == 0:
+            return ("sphere", {"radius": u(0.2, 1.0).clone()})
+        if k == 1:
+            return ("box", {"halfsides": u(0.1, 0.9, 3)})
+        if k == 2:
+            return ("plane", {})
+        if k == 3:
+            return ("line", {"start": u(-1.0, 1.0, 3), "end": u(-1.0, 1.0, 3) + 0.5, "radius": u(0.05, 0.3).clone()})
+        if k == 4:
+            return ("disk", {"radius": u(0.3, 1.0).clone()})
+        return ("torus", {"radius1": u(0.5, 1.2).clone(), "radius2": u(0.05, 0.3).clone()})
+
+    if depth >= max_depth or float(torch.rand(1, generator=gen)) < 0.25:
+        return leaf()
+    k = int(torch.randint(0, 5, (1,), generator=gen))
+    if k == 0:
+        q = torch.nn.functional.normalize(torch.randn(4, generator=gen), dim=0) * u(0.9, 1.1)   # not normalised on purpose
+        return ("affine", {"translation": u(-1.0, 1.0, 3), "orientation": q}, random_spec(gen, depth + 1, max_depth))
+    if k == 1:
+        n = int(torch.randint(1, 5, (1,), generator=gen))
+        return ("smooth_union", {"blend_k": u(4.0, 30.0).clone()}, [random_spec(gen, depth + 1, max_depth) for _ in range(n)])
+    if k == 2:
+        n = int(torch.randint(1, 5, (1,), generator=gen))
+        return ("union", {}, [random_spec(gen, depth + 1, max_depth) for _ in range(n)])
+    if k == 3:
+        return ("rounding", {"rounding": u(0.0, 0.2).clone()}, random_spec(gen, depth + 1, max_depth))
+    return ("onion", {"radius": u(0.02, 0.2).clone()}, random_spec(gen, depth + 1, max_depth))
+
+
+def spec_has(spec, kind):
+    if spec[0] == kind:
+        return True
+    kids = spec[2] if len(spec) > 2 else []
+    kids = kids if isinstance(kids, list) else [kids]
+    return any(spec_has(c, kind) for c in kids)

@@ -618,3 +618,47 @@ def test_config2_whole_frame_sample_vs_oracle(cam_z):
             got = loop(q.to(DEV), t.to(DEV), mode, 1, steps)[:, ::stride, ::stride]
         mx, _ = H.report(f"config 2 z={cam_z} mode {mode}", got, want)
         assert mx == 0.0, (cam_z, mode, mx)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_trees_vs_oracle(seed):
+    """Random compositions of all 11 node types (nested affine / smooth-union / union / rounding /
+    onion, un-normalised quaternions, 1-child unions ...) through the interpreter: values at 1500
+    points and the gradients w.r.t. points and every parameter, vs the oracle."""
+    gen = torch.Generator().manual_seed(1000 + seed)
+    spec = O.map_spec(H.random_spec(gen), lambda x: x.clone().float().requires_grad_(True))
+    module = H.spec_to_module(spec).to(DEV)
+    pts = torch.rand(1500, 3, generator=gen) * 5 - 2.5
+    wts = torch.randn(1500, 1, generator=gen)
+    p_cpu = pts.clone().requires_grad_(True)
+    d_cpu = O.sdf_eval(spec, p_cpu)
+    (d_cpu * wts).sum().backward()
+    p_gpu = pts.to(DEV).requires_grad_(True)
+    d_gpu = module(p_gpu)
+    (d_gpu * wts.to(DEV)).sum().backward()
+    exact = not H.spec_has(spec, "smooth_union")
+    mx, _ = H.report(f"tree {seed}", d_gpu, d_cpu)
+    assert mx <= (0.0 if exact else 2e-5), (seed, mx)
+    gscale = max(1.0, p_cpu.grad.abs().max().item())
+    assert H.report("grad points", p_gpu.grad, p_cpu.grad)[0] <= 2e-5 * gscale
+    for (pname, want), (_, got) in zip(O.spec_parameters(spec), module.named_parameters()):
+        if want.grad is None:
+            assert got.grad is None or float(got.grad.abs().max()) == 0.0
+            continue
+        scale = max(1.0, want.grad.abs().max().item())
+        err = (got.grad.cpu() - want.grad).abs().max().item()
+        assert err <= 2e-4 * scale, (seed, pname, err, scale)
+    # and a short march + normals through the same tree (kinks, NaN-free or NaN-identical)
+    from ray_marching_amd.rendering.ray_marching import SDFMarcher, SDFNormals
+    o = torch.tensor([[0.0, 0.0, -4.0]]).expand(256, 3).contiguous()
+    v = torch.nn.functional.normalize(torch.rand(256, 3, generator=gen) - torch.tensor([0.5, 0.5, -0.5]), dim=-1)
+    with torch.no_grad():
+        spec_ng = O.map_spec(spec, lambda x: x.detach())
+        p_ref = O.march(spec_ng, o, v, 12)
+        n_ref, lap_ref = O.normals(spec_ng, p_ref, H.EPS)
+        p_got = SDFMarcher(module)(o.to(DEV), v.to(DEV), 12)
+        n_got, lap_got = SDFNormals(module, H.EPS).to(DEV)(p_got)
+    tol = 0.0 if exact else 1e-4
+    assert H.report("march", p_got, p_ref)[0] <= tol * max(1.0, float(torch.nan_to_num(p_ref, posinf=0, neginf=0).abs().max()))
+    if exact:
+        assert H.report("normals", n_got, n_ref)[0] == 0.0
