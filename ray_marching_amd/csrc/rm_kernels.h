@@ -376,10 +376,14 @@ RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float 
     g0 += gm; g1 += gm; g2 += gm; g3 += gm;
     gp = gp + sc.vjp(p, gs);
   }
-  gp = gp + sc.vjp(p + T.o[0], g0);
-  gp = gp + sc.vjp(p + T.o[1], g1);
-  gp = gp + sc.vjp(p + T.o[2], g2);
-  gp = gp + sc.vjp(p + T.o[3], g3);
+  // one rolled loop over the four taps: a single inlined VJP body instead of four (the backward frame
+  // kernel drops from 185 to fewer VGPRs and a quarter of the code)
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const V3 ok = (k == 0) ? T.o[0] : ((k == 1) ? T.o[1] : ((k == 2) ? T.o[2] : T.o[3]));
+    const float gk = (k == 0) ? g0 : ((k == 1) ? g1 : ((k == 2) ? g2 : g3));
+    gp = gp + sc.vjp(p + ok, gk);
+  }
   return gp;
 }
 
