@@ -408,9 +408,9 @@ struct Ins {
   int op, off, a0, a1;
 };
 
-// Interpreter over a program staged in LDS; instruction words are wave-uniform.
+// Interpreter; instruction words are wave-uniform (scalar loads when `code` points at global memory).
 struct RuntimeProgram {
-  const int4* code;  // LDS
+  const int4* code;
   int n;
   template <class S, class PT>
   RM_DEV void forward(S& s, const PT& P) const {

@@ -31,7 +31,7 @@ struct GenericCfg {
   static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_derived; }
 
   // returns the scene context; `store` must outlive it
-  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
+  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool scalar_fetch = false) {
     int pb = (sc.n_params + sc.n_derived + 3) & ~3;
     float* s_params = smem;
     int4* s_prog = reinterpret_cast<int4*>(smem + pb);
@@ -40,7 +40,12 @@ struct GenericCfg {
     store.base = s_store + threadIdx.x;
     store.stride = blockDim.x + 1;
     SceneT s;
-    s.prog.code = s_prog; s.prog.n = sc.n_instr;
+    // Instruction fetch: LDS broadcast read + readfirstlane in the forward kernels; in the backward
+    // kernels, where LDS is busy with the per-thread gradient accumulators, straight from the program
+    // buffer through the scalar cache (kernel-argument pointer + wave-uniform pc -> s_load_dwordx4).
+    // Measured on the interpreter: forward 1.66 ms (LDS) vs 1.82 (scalar); backward 2.44 vs 1.75.
+    s.prog.code = scalar_fetch ? reinterpret_cast<const int4*>(sc.program) : s_prog;
+    s.prog.n = sc.n_instr;
     s.P.p = s_params;
     s.st = &store;
     s.tape0 = sc.stack_floats;
@@ -64,7 +69,7 @@ struct StaticCfg {
   static constexpr int kAcc = Code::n_params + Code::n_derived;
   static RM_DEV int n_acc(const RmScene&) { return kAcc; }
 
-  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store) {
+  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool = false) {
     // the parameter block is still staged through LDS (raw + derived), the program is not
     float* s_params = smem;
     for (int i = threadIdx.x; i < Code::n_params; i += blockDim.x) s_params[i] = sc.params[i];
@@ -160,7 +165,7 @@ template <class Cfg>
 __global__ void __launch_bounds__(256) k_sdf_bwd(RmScene sc, const float* __restrict__ pts, const float* __restrict__ gd,
                           float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
   typename Cfg::Store store;
-  auto scene = Cfg::setup(sc, rm_smem, store);
+  auto scene = Cfg::setup(sc, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(sc);
   zero_accumulators<Cfg>(scene, n_acc);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
@@ -300,7 +305,7 @@ __global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __re
                             float* __restrict__ gpos, float* __restrict__ gdirs, float* __restrict__ partials,
                             int64_t n, int steps) {
   typename Cfg::Store store;
-  auto scene = Cfg::setup(sc, rm_smem, store);
+  auto scene = Cfg::setup(sc, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(sc);
   zero_accumulators<Cfg>(scene, n_acc);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(256) k_normals_bwd(RmScene sc, RmTetra tetra, 
                               const float* __restrict__ gn, const float* __restrict__ gl,
                               float* __restrict__ gpts, float* __restrict__ partials, int64_t n) {
   typename Cfg::Store store;
-  auto scene = Cfg::setup(sc, rm_smem, store);
+  auto scene = Cfg::setup(sc, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(sc);
   zero_accumulators<Cfg>(scene, n_acc);
   Tetra T = load_tetra(tetra);
@@ -898,7 +903,7 @@ __global__ void k_camera_bwd_finish(const float* __restrict__ partials, int bloc
 template <class Cfg>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
-  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(a.scene);
   zero_accumulators<Cfg>(scene, n_acc);
   Tetra T = load_tetra(a.tetra);
