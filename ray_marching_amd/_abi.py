@@ -77,10 +77,15 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
 def _load():
-    if not os.path.isfile(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950).  ray_marching_amd has no CPU or PyTorch fallback.")
+    from . import _build
+    if _build.library_is_stale():
+        # fresh checkout or edited kernels: build now if a compiler is here, otherwise fail loudly
+        if _build.hipcc() is None:
+            raise ImportError(
+                f"{LIB_PATH} is missing or older than its sources and hipcc is not available: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                "ray_marching_amd has no CPU or PyTorch fallback.")
+        _build.build_library()
     return bind(C.CDLL(LIB_PATH))
 
 

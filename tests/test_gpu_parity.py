@@ -23,6 +23,9 @@ def kernel_path(request, monkeypatch):
     from ray_marching_amd import specialize
     monkeypatch.setenv("RM_SPECIALIZE", "off" if request.param == "generic" else "auto")
     specialize._loaded.clear()
+    if request.param == "static" and not getattr(kernel_path, "_built", False):
+        specialize.prebuild_default_scenes()      # no-op when __graft_entry__.build() already made them
+        kernel_path._built = True
     yield request.param
     specialize._loaded.clear()
 
