@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-early-out", action="store_true")
     ap.add_argument("--linear-waves", action="store_true", help="64x1 pixels per wave instead of 8x8 tiles")
     ap.add_argument("--static-tiles", action="store_true", help="static tile striding instead of the atomic tile queues")
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast"],
+                    help="exact (default, headline): bit-faithful arithmetic; fast: opt-in 1-ulp sqrt + FMA contraction")
     ap.add_argument("--camera-z", type=float, default=-3.0, help="camera position (0,0,z); SURVEY 8d uses -3 and +1")
     ap.add_argument("--skip-backward", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary 2-stream pipelined measurement")
@@ -187,7 +189,7 @@ def main():
     h_total = H_TILE * world
     loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=h_total, focal_length=PX * H_TILE,
                       sensor_width=PX * W, sensor_height=PX * h_total, normals_eps=EPS,
-                      early_out=not args.no_early_out, tile8x8=not args.linear_waves, dynamic_tiles=not args.static_tiles).to(dev)
+                      early_out=not args.no_early_out, tile8x8=not args.linear_waves, dynamic_tiles=not args.static_tiles, precision=args.precision).to(dev)
     from ray_marching_amd.compiler import compiled_for
     specialised = compiled_for(loop.scene).specialised
     rows = (rank * H_TILE, (rank + 1) * H_TILE)
@@ -277,7 +279,7 @@ def main():
                                    "1920x1080 pinhole ray grid per GPU, 128 march iters, normal + Lambertian "
                                    "frames per step, fp32", "frames_per_step": len(MODES),
                        "rays_per_frame": rays_per_frame, "camera": [0.0, 0.0, args.camera_z],
-                       "early_out": not args.no_early_out, "wave_tile": "64x1" if args.linear_waves else "8x8",
+                       "early_out": not args.no_early_out, "wave_tile": "64x1" if args.linear_waves else "8x8", "arithmetic": args.precision,
                        "tile_schedule": "static stride" if args.static_tiles else "64 atomic queues + stealing",
                        "kernels": "per-scene specialised (StaticCfg)" if specialised else "generic LDS interpreter",
                        "parallelism": f"row-tiles x{world}" + (" + RCCL gather" if gather else "")},

@@ -102,6 +102,20 @@ def bind(lib):
 
 
 lib = _load()
+_fast = None
+
+
+def fast_lib():
+    """The opt-in 'fast' arithmetic build of the generic library (built on first use)."""
+    global _fast
+    if _fast is None:
+        from . import _build
+        _fast = bind(C.CDLL(_build.build_library(precision="fast")))
+    return _fast
+
+
+def generic_lib(precision: str = "exact"):
+    return lib if precision == "exact" else fast_lib()
 
 
 def check(code: int, what: str, from_lib=None):

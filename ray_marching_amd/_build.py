@@ -15,6 +15,19 @@ LIB_PATH = os.path.join(LIBDIR, "librm_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("rm_abi.hip", "rm_kernels.h", "rm_device.h")] + \
     [os.path.join(os.path.dirname(_HERE), "include", "rm_abi.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-shared", "-fPIC", "-std=c++17"]
+# opt-in "fast" arithmetic (RenderLoop(precision="fast")): 1-ulp v_sqrt_f32, reciprocal normalise, FMA
+# contraction.  Still fp32 throughout; no longer bit-identical with the reference's CPU op stream.
+HIPCC_FLAGS_FAST = ["--offload-arch=gfx950", "-O3", "-ffp-contract=fast", "-DRM_FAST_MATH", "-shared", "-fPIC",
+                    "-std=c++17"]
+LIB_PATH_FAST = os.path.join(LIBDIR, "librm_hip_fast.so")
+
+
+def variant(precision: str):
+    if precision == "exact":
+        return LIB_PATH, HIPCC_FLAGS
+    if precision == "fast":
+        return LIB_PATH_FAST, HIPCC_FLAGS_FAST
+    raise ValueError(f"precision must be 'exact' or 'fast', not {precision!r}")
 
 
 def hipcc():
@@ -32,26 +45,28 @@ def sources_hash() -> str:
     return h.hexdigest()
 
 
-def library_is_stale() -> bool:
+def library_is_stale(precision: str = "exact") -> bool:
     """Content-hash staleness (file times do not survive the repo snapshot to the GPU box)."""
-    stamp = LIB_PATH + ".srchash"
-    if not (os.path.isfile(LIB_PATH) and os.path.isfile(stamp)):
+    path, _ = variant(precision)
+    stamp = path + ".srchash"
+    if not (os.path.isfile(path) and os.path.isfile(stamp)):
         return True
     with open(stamp) as f:
         return f.read().strip() != sources_hash()
 
 
-def build_library(force: bool = False) -> str:
-    """hipcc rm_abi.hip -> ray_marching_amd/lib/librm_hip.so (in-tree so it travels to the GPU box)."""
-    if not force and not library_is_stale():
-        return LIB_PATH
+def build_library(force: bool = False, precision: str = "exact") -> str:
+    """hipcc rm_abi.hip -> ray_marching_amd/lib/librm_hip[_fast].so (in-tree so it travels to the GPU box)."""
+    path, flags = variant(precision)
+    if not force and not library_is_stale(precision):
+        return path
     cc = hipcc()
     if cc is None:
-        raise RuntimeError("hipcc not found: cannot build librm_hip.so")
+        raise RuntimeError(f"hipcc not found: cannot build {os.path.basename(path)}")
     os.makedirs(LIBDIR, exist_ok=True)
-    tmp = LIB_PATH + f".tmp{os.getpid()}"
-    subprocess.run([cc, *HIPCC_FLAGS, os.path.join(CSRC, "rm_abi.hip"), "-o", tmp], check=True, cwd=CSRC)
-    os.replace(tmp, LIB_PATH)
-    with open(LIB_PATH + ".srchash", "w") as f:
+    tmp = path + f".tmp{os.getpid()}"
+    subprocess.run([cc, *flags, os.path.join(CSRC, "rm_abi.hip"), "-o", tmp], check=True, cwd=CSRC)
+    os.replace(tmp, path)
+    with open(path + ".srchash", "w") as f:
         f.write(sources_hash())
-    return LIB_PATH
+    return path

@@ -40,13 +40,17 @@ class CompiledScene:
     _packed: dict = field(default_factory=dict)
     _lib: object = None
 
-    def lib(self, backward: bool = False):
+    def lib(self, backward: bool = False, precision: str = "exact"):
         """Kernel library for this scene: the per-scene specialised build when one is available
         (ray_marching_amd/specialize.py), else the generic interpreter library.  Backward of
-        scenes with many parameters always uses the generic library (accumulators in LDS)."""
+        scenes with many parameters always uses the generic library (accumulators in LDS).
+        ``precision="fast"`` selects the opt-in fast-arithmetic builds."""
         from . import specialize
+        generic = _abi.generic_lib(precision)
         if backward and not specialize.static_backward(self):
-            return _abi.lib
+            return generic
+        if precision != "exact":
+            return specialize.load(self, precision) or generic
         if self._lib is None:
             self._lib = specialize.load(self) or _abi.lib
         if self._lib is _abi.lib and specialize.note_interpreted_launch(self):

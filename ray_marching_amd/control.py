@@ -45,7 +45,7 @@ class CapturedFrame:
 
         def frame():
             return ops.Render.apply(self.params, self.q, self.t, self.cs, rp, rd, loop.normals.tetra(), cmap,
-                                    self.mode, self.degree, self.steps, rows, flags, None)
+                                    self.mode, self.degree, self.steps, rows, flags, None, loop.precision)
 
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
@@ -76,7 +76,7 @@ class RenderLoop(nn.Module):
     def __init__(self, scene, num_cameras: int = 1, px_width: int = 800, px_height: int = 800,
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
                  normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True,
-                 dynamic_tiles: bool = True):
+                 dynamic_tiles: bool = True, precision: str = "exact"):
         super().__init__()
         self.scene = scene
         self.px_width = px_width
@@ -90,6 +90,9 @@ class RenderLoop(nn.Module):
         self.early_out = early_out
         self.tile8x8 = tile8x8
         self.dynamic_tiles = dynamic_tiles
+        if precision not in ("exact", "fast"):
+            raise ValueError("precision must be 'exact' (bit-faithful to the reference's CPU op stream, default) or 'fast'")
+        self.precision = precision
         self._f32_cache = {}
 
     def _f32_buffer(self, name: str) -> Tensor:
@@ -130,7 +133,8 @@ class RenderLoop(nn.Module):
         cmap = self._cmap_f32(rp.device) if mode in (6, 7) else None
         image = ops.Render.apply(cs.pack_params(rp.device), orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
-                                 ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax)
+                                 ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
+                                 self.precision)
         if mode in (6, 7) and self.shader.cyclic_cmap.dtype == torch.float64:
             return image.double()  # reference: fp32 brightness * float64 colormap -> float64 image
         out_dtype = self.camera.ray_positions.dtype

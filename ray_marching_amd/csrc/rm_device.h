@@ -51,7 +51,9 @@ RM_DEV V3 cross(V3 a, V3 b) {
 // v_sqrt's 1-ulp error; 9 instructions instead of 15.  (hipcc lowers __fsqrt_rn to the bare
 // 1-ulp v_sqrt_f32 -- it is NOT correctly rounded; measured, see DESIGN.md.)
 RM_DEV float rm_sqrt(float x) {
-#ifdef RM_LIBM_SQRT
+#if defined(RM_FAST_MATH)
+  return __builtin_amdgcn_sqrtf(x);   // opt-in "fast" build: bare v_sqrt_f32 (1 ulp), see DESIGN.md
+#elif defined(RM_LIBM_SQRT)
   return __builtin_sqrtf(x);
 #else
   float r = __builtin_amdgcn_sqrtf(x);
@@ -551,7 +553,12 @@ RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre
              (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
              (T.inv[6] * d1 + T.inv[7] * d2) + T.inv[8] * d3);
   float nu = norm3(u);              // F.normalize(eps=0): u / |u|, 0/0 = NaN like the reference
+#ifdef RM_FAST_MATH
+  float inv = __builtin_amdgcn_rcpf(nu);
+  n = mk3(u.x * inv, u.y * inv, u.z * inv);
+#else
   n = mk3(u.x / nu, u.y / nu, u.z / nu);
+#endif
   float mean = (((f0 + f1) + f2) + f3) / 4.0f;
   lap = (centre - mean) * T.lap_scale;
 }

@@ -272,7 +272,8 @@ class Render(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions,
-                tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax):
+                tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
+                precision: str = "exact"):
         _require_device(ray_positions, "camera buffers")
         _require_device(orientation, "orientations")
         dev = ray_positions.device
@@ -297,10 +298,11 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(ray_positions, ray_directions)
             _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
-            _ck(cs, cs.lib().rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
+            _abi.check(cs.lib(False, precision).rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
                                               _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
                                               _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
-                                              mode, degree, steps, r0, r1, flags, stream), "rm_render_forward")
+                                              mode, degree, steps, r0, r1, flags, stream), "rm_render_forward",
+                       cs.lib(False, precision))
             if mode in _GLOBAL_MODES:
                 if allreduce_minmax is not None:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
@@ -312,6 +314,7 @@ class Render(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(prm, q, t, ray_positions, ray_directions, p_final, traj, nexec)
             ctx.cs, ctx.tetra, ctx.mode, ctx.steps, ctx.rows, ctx.flags = cs, tetra, mode, steps, (r0, r1), flags
+            ctx.precision = precision
         return image
 
     @staticmethod
@@ -330,13 +333,13 @@ class Render(torch.autograd.Function):
             need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             gpos = torch.empty_like(p_final) if need_pose else None
             gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
-            _ck(cs, cs.lib(True).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
+            _abi.check(cs.lib(True, ctx.precision).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
                                                ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags, stream),
-                "rm_render_backward")
+                       "rm_render_backward", cs.lib(True, ctx.precision))
         gq = gt = None
         if need_pose:
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         gp_out = gprm[: prm.numel()] if ctx.needs_input_grad[0] else None
-        return (gp_out, gq, gt) + (None,) * 11
+        return (gp_out, gq, gt) + (None,) * 12

@@ -665,3 +665,47 @@ def test_random_scene_trees_vs_oracle(seed):
     assert H.report("march", p_got, p_ref)[0] <= tol * max(1.0, float(torch.nan_to_num(p_ref, posinf=0, neginf=0).abs().max()))
     if exact:
         assert H.report("normals", n_got, n_ref)[0] == 0.0
+
+
+def test_fast_precision_is_within_tolerance_of_the_reference():
+    """Opt-in precision="fast" (1-ulp v_sqrt_f32, reciprocal normalise, FMA contraction; still fp32).
+    Not bit-exact by construction; the contract is north_star's: pixels within 1e-5 (a 1-ulp change can
+    move a silhouette ray to another object, so a small fraction of edge pixels is allowed to differ) and
+    parameter gradients within 1e-4."""
+    g = H.gold("f4_scene2_90x160_s128_tilt.npz")
+    h, w = (int(x) for x in g["hw"])
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, precision="fast")
+    from ray_marching_amd.compiler import compiled_for
+    assert compiled_for(loop.scene).lib(False, "fast") is not compiled_for(loop.scene).lib(False, "exact")
+    q, t = torch.from_numpy(g["q"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    for m in (0, 4):
+        with torch.no_grad():
+            img = loop(q, t, m, 1, int(g["steps"]))
+        want = g[f"mode{m}"]
+        mx, frac = H.report(f"fast mode {m}", img[..., : want.shape[-1]], want)
+        print(f"fast arithmetic, mode {m}: max|err|={mx:.3g}, fraction of values beyond 1e-5: {frac:.3g}")
+        assert frac <= 2e-3, (m, mx, frac)
+    # whole 1080p frame sample vs the oracle
+    hh, ww, steps, stride = 1080, 1920, 128, 8
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), hh, ww, precision="fast")
+    qq = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); tt = torch.tensor([[0.0, 0.0, -3.0]])
+    bufs = O.camera_buffers(1, ww, hh, H.PX * hh, H.PX * ww, H.PX * hh)
+    sub = tuple(b[:, ::stride, ::stride].contiguous() for b in bufs)
+    with torch.no_grad():
+        want = O.render(O.scene_test2(), sub, qq, tt, 4, 1, steps, H.EPS)
+        got = loop(qq.to(DEV), tt.to(DEV), 4, 1, steps)[:, ::stride, ::stride]
+    mx, frac = H.report("fast 1080p", got, want)
+    print(f"fast arithmetic, 1080p sample: max|err|={mx:.3g}, fraction beyond 1e-5: {frac:.3g}")
+    assert frac <= 2e-3
+    # gradients (config-4 shape fixture)
+    gb = H.gold("f5_backward.npz")
+    h, w = (int(x) for x in gb["hw"])
+    module = H.spec_to_module(O.scene_test1_closed())
+    loop = H.make_loop(module, h, w, precision="fast")
+    q, t = torch.from_numpy(gb["q"]).to(DEV), torch.from_numpy(gb["t"]).to(DEV)
+    img = loop(q, t, 0, 1, int(gb["steps"]))
+    (img[..., :1] - torch.from_numpy(gb["target"]).to(DEV)).pow(2).mean().backward()
+    worst = max((p.grad.cpu() - torch.from_numpy(gb[f"lambert_mse_f32_grad:{n}"])).abs().max().item()
+                for n, p in module.named_parameters())
+    print(f"fast arithmetic: worst parameter-gradient error {worst:.3g}")
+    assert worst <= 1e-4
