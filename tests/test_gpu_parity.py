@@ -4,6 +4,8 @@ Tolerance (north_star): forward pixels within 1e-5 fp32.  The kernels follow the
 reference's ATen op order with FMA contraction off, so most outputs are in fact bit-exact;
 the asserts below use 1e-5 (and say where a tighter bound holds).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -712,3 +714,38 @@ def test_fast_precision_is_within_tolerance_of_the_reference():
                      for n, _ in module.named_parameters())
     print(f"fast arithmetic: worst parameter-gradient error {worst:.3g} (reference fp32-vs-fp64 spread {ref_spread:.3g})")
     assert worst <= ref_spread and worst <= 1e-3
+
+
+@pytest.mark.parametrize("seed", [4, 17, 21])
+def test_jit_specialised_random_trees_match_interpreter(seed, monkeypatch, tmp_path):
+    """The compile-time specialisation of an arbitrary topology (nested unions / smooth unions / affine
+    chains; built here with hipcc, ~10 s each) must reproduce the interpreter bit for bit: values, a
+    short frame, and (to summation order) gradients."""
+    from ray_marching_amd import _abi, specialize
+    from ray_marching_amd.compiler import compile_scene, compiled_for
+    if specialize._hipcc() is None or not os.path.exists(specialize._hipcc()):
+        pytest.skip("hipcc not available on this box")
+    monkeypatch.setattr(specialize, "SPEC_DIR", str(tmp_path))
+    gen = torch.Generator().manual_seed(1000 + seed)
+    spec = O.map_spec(H.random_spec(gen), lambda x: x.clone().float())
+    results = {}
+    for policy in ("off", "jit"):
+        monkeypatch.setenv("RM_SPECIALIZE", policy)
+        specialize._loaded.clear()
+        module = H.spec_to_module(spec).to(DEV)
+        cs = compiled_for(module)
+        assert cs.specialised == (policy == "jit")
+        pts = (torch.rand(4096, 3, generator=torch.Generator().manual_seed(seed)) * 5 - 2.5).to(DEV).requires_grad_(True)
+        d = module(pts)
+        d.sum().backward()
+        loop = H.make_loop(module, 40, 56)
+        q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -4.0]], device=DEV)
+        with torch.no_grad():
+            img = loop(q, t, 4, 1, 24)
+        results[policy] = (d.detach(), pts.grad.clone(), img, [p.grad.clone() for p in module.parameters()])
+    specialize._loaded.clear()
+    a, b = results["off"], results["jit"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(torch.nan_to_num(a[2], nan=-7.0), torch.nan_to_num(b[2], nan=-7.0))
+    for ga, gb in zip(a[3], b[3]):
+        assert (ga - gb).abs().max().item() <= 1e-5 * max(1.0, ga.abs().max().item())
