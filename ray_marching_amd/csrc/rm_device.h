@@ -541,13 +541,9 @@ RM_DEV Tetra load_tetra(const RmTetra& t) {
   return r;
 }
 
-// SDFNormals.forward (ray_marching.py:115-125).
+// SDFNormals.forward (ray_marching.py:115-125).  `centre` = scene(p) is supplied by the caller.
 template <class SceneT>
-RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre, V3& n, float& lap) {
-  float f0 = sc.eval(p + T.o[0]);
-  float f1 = sc.eval(p + T.o[1]);
-  float f2 = sc.eval(p + T.o[2]);
-  float f3 = sc.eval(p + T.o[3]);
+RM_DEV void normals_from_taps(const Tetra& T, float f0, float f1, float f2, float f3, float centre, V3& n, float& lap) {
   float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
   V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
              (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
@@ -561,6 +557,26 @@ RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre
 #endif
   float mean = (((f0 + f1) + f2) + f3) / 4.0f;
   lap = (centre - mean) * T.lap_scale;
+}
+
+// The four tap evaluations run as ONE rolled loop (a single inlined copy of the scene evaluator
+// instead of four: the interpreter body is large and the instruction cache is shared by two CUs).
+template <class SceneT>
+RM_DEV void eval_taps(const SceneT& sc, const Tetra& T, V3 p, float& f0, float& f1, float& f2, float& f3) {
+  f0 = f1 = f2 = f3 = 0.0f;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const V3 ok = (k == 0) ? T.o[0] : ((k == 1) ? T.o[1] : ((k == 2) ? T.o[2] : T.o[3]));
+    const float fk = sc.eval(p + ok);
+    f0 = (k == 0) ? fk : f0; f1 = (k == 1) ? fk : f1; f2 = (k == 2) ? fk : f2; f3 = (k == 3) ? fk : f3;
+  }
+}
+
+template <class SceneT>
+RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre, V3& n, float& lap) {
+  float f0, f1, f2, f3;
+  eval_taps(sc, T, p, f0, f1, f2, f3);
+  normals_from_taps<SceneT>(T, f0, f1, f2, f3, centre, n, lap);
 }
 
 // monotone float <-> uint map for atomic min/max

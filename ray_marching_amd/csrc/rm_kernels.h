@@ -357,10 +357,8 @@ __global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, 
 // VJP of normals_forward.  gn: dL/dn, gl: dL/dlap.  Returns dL/dp.
 template <class SceneT>
 RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float gl, bool need_lap) {
-  float f0 = sc.eval(p + T.o[0]);
-  float f1 = sc.eval(p + T.o[1]);
-  float f2 = sc.eval(p + T.o[2]);
-  float f3 = sc.eval(p + T.o[3]);
+  float f0, f1, f2, f3;
+  eval_taps(sc, T, p, f0, f1, f2, f3);
   float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
   V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
              (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
