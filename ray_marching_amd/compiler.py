@@ -210,9 +210,18 @@ def compile_scene(module: nn.Module) -> CompiledScene:
 
 
 def structure_key(module: nn.Module):
-    """Cheap key that changes when the tree topology or parameter identity changes."""
-    return tuple((type(m).__name__, id(m)) for m in module.modules()) + \
-        tuple(id(p) for p in module.parameters())
+    """Cheap fingerprint that changes when the tree topology or parameter identity changes: the ids of
+    every sub-module and parameter, walked through ``_modules`` / ``_parameters`` directly
+    (``module.parameters()`` builds dotted name strings on every call: 25 us for a 7-node scene)."""
+    out = []
+    stack = [module]
+    while stack:
+        m = stack.pop()
+        out.append(id(m))
+        for p in m._parameters.values():
+            out.append(id(p))
+        stack.extend(m._modules.values())
+    return tuple(out)
 
 
 def compiled_for(module: nn.Module) -> CompiledScene:

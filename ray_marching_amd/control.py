@@ -44,7 +44,7 @@ class CapturedFrame:
         flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles)
 
         def frame():
-            return ops.Render.apply(self.params, self.q, self.t, self.cs, rp, rd, loop.normals.tetra(), cmap,
+            return ops.render_frame(self.params, self.q, self.t, self.cs, rp, rd, loop.normals.tetra(), cmap,
                                     self.mode, self.degree, self.steps, rows, flags, None, loop.precision)
 
         with torch.no_grad():
@@ -131,7 +131,7 @@ class RenderLoop(nn.Module):
         rd = self._f32_buffer("ray_directions")
         cs = compiled_for(self.scene)
         cmap = self._cmap_f32(rp.device) if mode in (6, 7) else None
-        image = ops.Render.apply(cs.pack_params(rp.device), orientations, translations, cs, rp, rd,
+        image = ops.render_frame(cs.pack_params(rp.device), orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
                                  self.precision)

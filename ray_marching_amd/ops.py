@@ -274,6 +274,15 @@ class Render(torch.autograd.Function):
     def forward(ctx, params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions,
                 tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
                 precision: str = "exact"):
+        return Render.run(ctx, ctx.needs_input_grad, params, orientation, translation, cs, ray_positions,
+                          ray_directions, tetra, cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision)
+
+    @staticmethod
+    def run(ctx, needs_input_grad, params, orientation, translation, cs: CompiledScene, ray_positions,
+            ray_directions, tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
+            precision: str = "exact"):
+        """Body of the forward pass.  ``ctx`` is None for inference frames, which skip the autograd
+        machinery altogether (render_frame below)."""
         _require_device(ray_positions, "camera buffers")
         _require_device(orientation, "orientations")
         dev = ray_positions.device
@@ -285,7 +294,7 @@ class Render(torch.autograd.Function):
         r0, r1 = rows if rows is not None else (0, h)
         nrows = r1 - r0
         R = n * nrows * w
-        need_grad = any(ctx.needs_input_grad[:3])
+        need_grad = any(needs_input_grad[:3])
         if need_grad and mode not in (0, 4):
             raise NotImplementedError(f"fused backward exists for shader modes 0 (lambertian) and 4 (normal), not {mode}")
         image = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
@@ -343,3 +352,17 @@ class Render(torch.autograd.Function):
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         gp_out = gprm[: prm.numel()] if ctx.needs_input_grad[0] else None
         return (gp_out, gq, gt) + (None,) * 12
+
+
+_NO_GRAD = (False, False, False)
+
+
+def render_frame(params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions, tetra, cmap,
+                 mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax, precision: str = "exact"):
+    """One frame.  Goes through autograd only when something can receive a gradient; an inference frame
+    calls the launch code directly (autograd.Function.apply costs ~20 us per call even under no_grad)."""
+    if torch.is_grad_enabled() and (params.requires_grad or orientation.requires_grad or translation.requires_grad):
+        return Render.apply(params, orientation, translation, cs, ray_positions, ray_directions, tetra, cmap, mode,
+                            degree, steps, rows, flags, allreduce_minmax, precision)
+    return Render.run(None, _NO_GRAD, params, orientation, translation, cs, ray_positions, ray_directions, tetra,
+                      cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision)
