@@ -126,6 +126,25 @@ def pipelined_probe(loop, q, t, rows, dev, rays_per_frame, frames=40, nstreams=2
             "value": rays_per_frame * frames / dt / 1e6, "unit": "Mrays/s"}
 
 
+def other_camera_probe(loop, q, rows, dev, rays_per_frame, timed_z, frames=20):
+    """SURVEY 8(d) names two cameras for config 2: (0,0,-3), outside the torus (the timed one by default),
+    and the reference's default pose (0,0,1) (main.py:46), inside the torus tube, where more rays never
+    settle.  Report the one that was not timed, measured the same way (serial, one stream)."""
+    z = 1.0 if timed_z != 1.0 else -3.0
+    t = torch.tensor([[0.0, 0.0, z]], device=dev)
+    with torch.no_grad():
+        for i in range(4):
+            loop(q, t, MODES[i % len(MODES)], 1, STEPS_MARCH, rows=rows)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            loop(q, t, MODES[i % len(MODES)], 1, STEPS_MARCH, rows=rows)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"camera": [0.0, 0.0, z], "ms_per_frame": dt / frames * 1e3, "value": rays_per_frame * frames / dt / 1e6,
+            "unit": "Mrays/s"}
+
+
 def backward_probe(dev):
     """Secondary metric 'fwd+bwd ms/frame' (BASELINE config 4 shape): closed make_test_scene,
     512x512, 64 steps, Lambertian MSE loss, gradients of all 40 scene parameters."""
@@ -295,6 +314,7 @@ def main():
                                   "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer"}},
         }
         if world == 1 and not args.no_pipelined:
+            out["other_camera"] = other_camera_probe(loop, q, rows, dev, rays_per_frame, args.camera_z)
             out["pipelined"] = pipelined_probe(loop, q, t, rows, dev, rays_per_frame)
         if not args.skip_backward:
             log("backward probe (config 4 shape) ...")
