@@ -240,3 +240,35 @@ def test_background_specialisation_policy(monkeypatch, tmp_path):
     monkeypatch.setenv("RM_SPECIALIZE", "off")
     assert compile_scene(SDFRounding(SDFDisk(0.7), 0.05)).lib() is _abi.lib
     specialize._loaded.clear(); specialize._uses.clear()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+    leg may touch it.  The product package must not (no CPU fallback can hide behind it), and it must not
+    read the reference tree either."""
+    import ast
+    pkg = os.path.join(ROOT, "ray_marching_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if not name.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, name)
+            src = open(path).read()
+            tree = ast.parse(src)
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or ""]
+                for m in mods:
+                    assert not m.split(".")[0] == "oracle", f"{path} imports {m}"
+            assert "/root/reference" not in src, f"{path} mentions the reference tree"
+    # bench.py: the oracle appears only inside cpu_baseline(); __graft_entry__: only inside smoke()
+    for fname, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(ROOT, fname)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle" for n in ast.walk(fn))
+            assert not uses or fn.name == allowed, f"{fname}:{fn.name} imports the oracle"
+        top_level = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        assert not any((getattr(n, "module", "") or "").startswith("oracle") for n in top_level)
