@@ -160,7 +160,11 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
     case RM_OP_BOX: {  // |relu(q)| + min(max(q),0), q = |p| - h
       float qx = fabsf(s.p.x) - P[off], qy = fabsf(s.p.y) - P[off + 1], qz = fabsf(s.p.z) - P[off + 2];
       float m = t_max(t_max(qx, qy), qz);
-      float nr = norm3(mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz)));
+      // Inside the box every q <= 0, so relu(q) = (+0,+0,+0) and its norm is exactly +0: when that holds
+      // for the whole wave (rays inside a room shell: always) the norm -- 3 max, mul, 2 fma and the
+      // 9-instruction exact sqrt -- is skipped.  NaN fails (m <= 0) and takes the full path.
+      float nr = 0.0f;
+      if (!__all(m <= 0.0f)) nr = norm3(mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz)));
       s.d = nr + ((m < 0.0f) ? m : 0.0f);
     } break;
     case RM_OP_PLANE:
