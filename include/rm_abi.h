@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 7
+#define RM_ABI_VERSION 8
 
 enum {
   RM_OK = 0,
@@ -54,14 +54,18 @@ enum {
   RM_OP_AFFINE_PUSH = 7,   /* P: translation[3] orientation[4]   transformations.py:33-42 */
   RM_OP_AFFINE_POP = 8,    /* P: same offset as the matching PUSH */
   RM_OP_UNION_BEGIN = 9,   /*                               transformations.py:90-94 */
-  RM_OP_FOLD_MIN = 10,     /* aux0 = tape slot */
+  RM_OP_FOLD_MIN = 10,     /* aux0 = tape slot; aux1 = distance back to its CULL_MIN (0 = none) */
   RM_OP_UNION_END = 11,    /* aux0 = first tape slot, aux1 = child count */
   RM_OP_SMOOTH_BEGIN = 12, /*                               transformations.py:67-71 */
   RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot */
   RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count */
   RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
   RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
-  RM_OP__COUNT = 17
+  RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: aux0 = derived offset of its bounding sphere
+                              {cx,cy,cz,R}; aux1 = (n << 8) | slot, n = instructions up to and including the
+                              child's FOLD_MIN (whose aux1 = n).  Skips the child when it cannot lower the
+                              running minimum for any ray of the wave (exact) */
+  RM_OP__COUNT = 18
 };
 
 typedef struct RmScene {

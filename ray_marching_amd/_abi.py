@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
 
@@ -18,6 +18,7 @@ OP_AFFINE_PUSH, OP_AFFINE_POP = 7, 8
 OP_UNION_BEGIN, OP_FOLD_MIN, OP_UNION_END = 9, 10, 11
 OP_SMOOTH_BEGIN, OP_FOLD_LSE, OP_SMOOTH_END = 12, 13, 14
 OP_ROUND, OP_ONION = 15, 16
+OP_CULL_MIN = 17
 
 FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES = 1, 2, 4
 WORK_WORDS = 64 + 64 * 32   # RM_WORK_WORDS

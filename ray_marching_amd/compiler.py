@@ -21,8 +21,45 @@ import torch.nn as nn
 
 from . import _abi
 
+import os
+
 # backward-pass stack cost of each frame kind, in floats (forward uses fewer)
 _STACK_UNION, _STACK_SMOOTH, _STACK_AFFINE = 2, 2, 6
+
+
+# rough VALU cost of evaluating a subtree (instructions per ray), used only to decide whether a cull test
+# (~9 instructions when it fails) is worth emitting in front of it
+_LEAF_COST = {"sphere": 13, "box": 22, "plane": 1, "line": 30, "disk": 20, "torus": 24}
+_CULL_MIN_CHILD_COST = 40
+
+
+def _cost(node) -> int:
+    kind = getattr(node, "_rm_kind", None)
+    if kind in _LEAF_COST:
+        return _LEAF_COST[kind]
+    if kind == "affine":
+        return 25 + _cost(node.sdf)
+    if kind in ("rounding", "onion"):
+        return 1 + _cost(node.sdf)
+    if kind == "union":
+        return sum(_cost(c) + 1 for c in node.sdfs)
+    if kind == "smooth_union":
+        return sum(_cost(c) + 25 for c in node.sdfs) + 20
+    return 0
+
+
+def _boundable(node) -> bool:
+    """Can the kernels derive a bounding sphere for this subtree (csrc/rm_device.h: subtree_bound)?
+    Everything except an SDFPlane somewhere inside; whether the bound is finite is decided on the device
+    from the live parameter values."""
+    kind = getattr(node, "_rm_kind", None)
+    if kind in ("sphere", "box", "line", "disk", "torus"):
+        return True
+    if kind in ("affine", "rounding", "onion"):
+        return _boundable(node.sdf)
+    if kind in ("union", "smooth_union"):
+        return all(_boundable(c) for c in node.sdfs)
+    return False
 
 
 @dataclass
@@ -109,6 +146,9 @@ class _Emitter:
         self.n_derived = 0
         self.depth = 0
         self.max_depth = 0
+        self.cull = os.environ.get("RM_CULL", "1") != "0"    # RM_CULL=0: no CULL_MIN instructions (A/B tests)
+        # RM_CULL_MIN_COST=0: a cull test in front of every boundable child, however cheap (stress tests)
+        self.cull_min_cost = int(os.environ.get("RM_CULL_MIN_COST", _CULL_MIN_CHILD_COST))
 
     def off(self, *params):
         """Offset of the first parameter; the rest must follow contiguously."""
@@ -167,8 +207,20 @@ def _emit(node, em: _Emitter, n_params: int):
         em.ins(A.OP_SMOOTH_BEGIN if smooth else A.OP_UNION_BEGIN)
         em.push(_STACK_SMOOTH if smooth else _STACK_UNION)
         for i, child in enumerate(kids):
+            # exact culling of min-union children (never the first: nothing to compare with yet)
+            cull_at = None
+            if (not smooth and i > 0 and base + i < 64 and em.cull and _cost(child) >= em.cull_min_cost
+                    and _boundable(child)):
+                cull_at = len(em.code)
+                em.ins(A.OP_CULL_MIN, 0, n_params + em.n_derived, 0)      # aux1 patched below
+                em.n_derived += 4
             _emit(child, em, n_params)
-            em.ins(A.OP_FOLD_LSE if smooth else A.OP_FOLD_MIN, koff, base + i)
+            if cull_at is not None:
+                skip = len(em.code) - cull_at
+                em.code[cull_at] = (A.OP_CULL_MIN, 0, em.code[cull_at][2], (skip << 8) | (base + i))
+                em.ins(A.OP_FOLD_MIN, 0, base + i, skip)
+            else:
+                em.ins(A.OP_FOLD_LSE if smooth else A.OP_FOLD_MIN, koff, base + i)
         em.pop(_STACK_SMOOTH if smooth else _STACK_UNION)
         em.ins(A.OP_SMOOTH_END if smooth else A.OP_UNION_END, koff, base, len(kids))
     elif kind == "rounding":

@@ -403,7 +403,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
 int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_params, int32_t n_derived,
                         int32_t stack_floats, int32_t n_slots) {
   if (!host_program || n_instr <= 0) return fail(RM_E_PROGRAM, "empty program");
-  static const int psize[RM_OP__COUNT] = {0, 1, 3, 0, 7, 1, 2, 7, 7, 0, 0, 0, 0, 1, 1, 1, 1};
+  static const int psize[RM_OP__COUNT] = {0, 1, 3, 0, 7, 1, 2, 7, 7, 0, 0, 0, 0, 1, 1, 1, 1, 0};
   int depth_f = 0, depth_b = 0, max_f = 0, max_b = 0, values = 0;
   for (int i = 0; i < n_instr; ++i) {
     const int32_t* w = host_program + 4 * i;
@@ -430,7 +430,20 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_FOLD_MIN: case RM_OP_FOLD_LSE: case RM_OP_ONION:
         if (a0 < 0 || a0 >= n_slots) return fail(RM_E_PROGRAM, "instr %d: slot out of range", i);
         if (op != RM_OP_ONION) values--;
+        if (op == RM_OP_FOLD_MIN && a1 != 0) {
+          const int c = i - a1;
+          if (a1 < 0 || c < 0 || host_program[4 * c] != RM_OP_CULL_MIN || host_program[4 * c + 3] != ((a1 << 8) | a0))
+            return fail(RM_E_PROGRAM, "instr %d: FOLD_MIN does not point back at its CULL_MIN", i);
+        }
         break;
+      case RM_OP_CULL_MIN: {
+        const int skip = a1 >> 8, slot = a1 & 255;
+        if (a0 < n_params || a0 + 4 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: bound out of range", i);
+        if (skip < 2 || i + skip >= n_instr || slot >= 64 || slot >= n_slots ||
+            host_program[4 * (i + skip)] != RM_OP_FOLD_MIN || host_program[4 * (i + skip) + 2] != slot ||
+            host_program[4 * (i + skip) + 3] != skip)
+          return fail(RM_E_PROGRAM, "instr %d: CULL_MIN does not match its FOLD_MIN", i);
+      } break;
       default: break;
     }
     if (depth_f < 0 || depth_b < 0 || values < 0 || values > 1)

@@ -149,7 +149,23 @@ struct Fwd {
   int tape0;   // index of tape slot 0 inside the store
   Store* st;
   bool record; // record every fold/onion input (needed by the reverse sweep)
+  unsigned long long culled;  // wave-uniform: bit s set = the union child folding into tape slot s was skipped
 };
+
+// Exact culling of a min-union child (RM_OP_CULL_MIN).  The derived block holds a bounding sphere
+// (centre c, radius R; R = +inf when the subtree has none) of the child's surface in the union's frame,
+// computed from the live parameters at staging time, so child(p) >= |p - c| - R.  If that lower bound --
+// taken with a safety margin far above fp32 rounding -- is >= the running minimum `acc` of the children
+// evaluated so far for ALL 64 rays, the child cannot lower the minimum and cannot win a tie (ties go to
+// the FIRST child), so skipping it leaves value, winner and gradients bit-identical.
+template <class S, class PT>
+RM_DEV bool cull_min_test(const S& s, const PT& P, int a0) {
+  V3 c = P.v3(a0);
+  float K = P[a0 + 3];               // 1.0001 R + 1e-4, folded at staging (derive_constants)
+  V3 d = s.p - c;
+  float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
+  return __all(__builtin_fmaf(dist, 0.9998f, -K) >= s.acc);   // NaN anywhere (K is NaN for an unbounded child): false
+}
 
 template <class S, class PT>
 RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
@@ -250,6 +266,7 @@ struct Bwd {
   int tape0;
   int acc0;
   Store* st;
+  unsigned long long culled;   // from the recording forward pass
 };
 
 template <class S>
@@ -424,14 +441,29 @@ struct RuntimeProgram {
   RM_DEV void forward(S& s, const PT& P) const {
     for (int pc = 0; pc < n; ++pc) {
       int4 w = code[pc];
-      fwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
+      const int op = uniform_i(w.x), off = uniform_i(w.y), a0 = uniform_i(w.z), a1 = uniform_i(w.w);
+      if (op == RM_OP_CULL_MIN) {            // a1 = (instructions up to and including the child's FOLD) << 8 | slot
+        if (cull_min_test(s, P, a0)) {
+          const int slot = a1 & 255;
+          if (s.record) { s.st->st(s.tape0 + slot, __builtin_inff()); s.culled |= 1ull << slot; }
+          pc += a1 >> 8;
+        }
+        continue;
+      }
+      fwd_op(s, P, op, off, a0, a1);
     }
   }
   template <class S, class PT>
   RM_DEV void backward(S& s, const PT& P) const {
     for (int pc = n - 1; pc >= 0; --pc) {
       int4 w = code[pc];
-      bwd_op(s, P, uniform_i(w.x), uniform_i(w.y), uniform_i(w.z), uniform_i(w.w));
+      const int op = uniform_i(w.x), off = uniform_i(w.y), a0 = uniform_i(w.z), a1 = uniform_i(w.w);
+      if (op == RM_OP_FOLD_MIN && a1 > 0 && ((s.culled >> a0) & 1ull)) {   // a1 = distance back to its CULL_MIN
+        s.g = 0.0f;
+        pc -= a1;                              // jump over the skipped child and its CULL_MIN
+        continue;
+      }
+      bwd_op(s, P, op, off, a0, a1);
     }
   }
 };
@@ -439,26 +471,48 @@ struct RuntimeProgram {
 // Compile-time program: Code::code[] is constexpr, recursion unrolls it.
 template <class Code>
 struct StaticProgram {
-  template <int PC, class S, class PT>
-  RM_DEV void fwd_from(S& s, const PT& P) const {
-    if constexpr (PC < Code::n) {
+  // executes instructions [PC, END)
+  template <int PC, int END, class S, class PT>
+  RM_DEV void fwd_range(S& s, const PT& P) const {
+    if constexpr (PC < END) {
       constexpr Ins i = Code::code[PC];
-      fwd_op(s, P, i.op, i.off, i.a0, i.a1);
-      fwd_from<PC + 1>(s, P);
+      if constexpr (i.op == RM_OP_CULL_MIN) {
+        constexpr int skip = i.a1 >> 8, slot = i.a1 & 255;
+        if (cull_min_test(s, P, i.a0)) {
+          if (s.record) { s.st->st(s.tape0 + slot, __builtin_inff()); s.culled |= 1ull << slot; }
+        } else {
+          fwd_range<PC + 1, PC + 1 + skip>(s, P);
+        }
+        fwd_range<PC + 1 + skip, END>(s, P);
+      } else {
+        fwd_op(s, P, i.op, i.off, i.a0, i.a1);
+        fwd_range<PC + 1, END>(s, P);
+      }
     }
   }
-  template <int PC, class S, class PT>
-  RM_DEV void bwd_from(S& s, const PT& P) const {
-    if constexpr (PC >= 0) {
+  // executes instructions (BEGIN, PC] in reverse order
+  template <int PC, int BEGIN, class S, class PT>
+  RM_DEV void bwd_range(S& s, const PT& P) const {
+    if constexpr (PC > BEGIN) {
       constexpr Ins i = Code::code[PC];
-      bwd_op(s, P, i.op, i.off, i.a0, i.a1);
-      bwd_from<PC - 1>(s, P);
+      if constexpr (i.op == RM_OP_FOLD_MIN && i.a1 > 0) {
+        if ((s.culled >> i.a0) & 1ull) {
+          s.g = 0.0f;
+        } else {
+          bwd_op(s, P, i.op, i.off, i.a0, i.a1);
+          bwd_range<PC - 1, PC - i.a1>(s, P);     // the child; PC - a1 is its CULL_MIN
+        }
+        bwd_range<PC - i.a1 - 1, BEGIN>(s, P);
+      } else {
+        if constexpr (i.op != RM_OP_CULL_MIN) bwd_op(s, P, i.op, i.off, i.a0, i.a1);
+        bwd_range<PC - 1, BEGIN>(s, P);
+      }
     }
   }
   template <class S, class PT>
-  RM_DEV void forward(S& s, const PT& P) const { fwd_from<0>(s, P); }
+  RM_DEV void forward(S& s, const PT& P) const { fwd_range<0, Code::n>(s, P); }
   template <class S, class PT>
-  RM_DEV void backward(S& s, const PT& P) const { bwd_from<Code::n - 1>(s, P); }
+  RM_DEV void backward(S& s, const PT& P) const { bwd_range<Code::n - 1, -1>(s, P); }
 };
 
 // Scene evaluation context shared by all kernels of one block.
@@ -473,6 +527,7 @@ struct Scene {
   RM_DEV float eval(V3 p, bool record = false) const {
     Fwd<Store> s;
     s.p = p; s.d = 0.0f; s.acc = __builtin_inff(); s.sp = 0; s.tape0 = tape0; s.st = st; s.record = record;
+    s.culled = 0ull;
     prog.forward(s, P);
     return s.d;
   }
@@ -481,11 +536,12 @@ struct Scene {
   RM_DEV V3 vjp(V3 p, float g, float* value = nullptr) const {
     Fwd<Store> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
+    f.culled = 0ull;
     prog.forward(f, P);
     if (value) *value = f.d;
     Bwd<Store> b;
     b.p = p; b.gp = mk3(0.0f, 0.0f, 0.0f); b.g = g; b.gframe = 0.0f; b.fval = 0.0f;
-    b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st;
+    b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st; b.culled = f.culled;
     prog.backward(b, P);
     return b.gp;
   }
@@ -496,23 +552,129 @@ struct Scene {
 // Derived constants (capsule AB and AB/|AB|^2, primitives.py:52-54) are
 // computed once per block instead of once per evaluation.
 // --------------------------------------------------------------------------
+// Bounding sphere (centre, radius) of the surface of the subtree encoded by instructions [begin, end),
+// in the frame in which that subtree is evaluated: subtree(p) >= |p - c| - R for every p.  R = +inf
+// when no finite bound is known (plane, strongly non-unit affine quaternion, non-positive blend_k, odd
+// parameters).  Runs once per block on one thread, from the parameters already staged in LDS.
+struct BoundFrame {
+  float cx, cy, cz, R;   // union frames: enclosing sphere of the children folded so far
+  int n;                 // children folded; -1 for an affine frame
+  int off;               // affine frame: parameter offset
+};
+
+constexpr int kBoundDepth = 12;
+
+template <class GetIns>
+RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float* out /*[4]*/, BoundFrame* st) {
+  constexpr int kDepth = kBoundDepth;
+  int sp = 0;
+  float cx = 0.0f, cy = 0.0f, cz = 0.0f, R = __builtin_inff();
+  const float inf = __builtin_inff();
+  bool overflow = false;
+  for (int pc = begin; pc < end && !overflow; ++pc) {
+    const int4 w = ins(pc);
+    const int op = w.x, off = w.y;
+    switch (op) {
+      case RM_OP_SPHERE: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_BOX: {
+        float hx = P[off], hy = P[off + 1], hz = P[off + 2];
+        cx = cy = cz = 0.0f;
+        R = (hx >= 0.0f && hy >= 0.0f && hz >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) : inf;
+      } break;
+      case RM_OP_PLANE: R = inf; break;
+      case RM_OP_LINE: {
+        const float* a = P + off;
+        float ls = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), le = sqrtf(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
+        cx = cy = cz = 0.0f;
+        R = (a[6] >= 0.0f) ? fmaxf(ls, le) + a[6] : inf;
+      } break;
+      case RM_OP_DISK: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_TORUS: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f && P[off + 1] >= 0.0f) ? P[off] + P[off + 1] : inf; break;
+      case RM_OP_ROUND: case RM_OP_ONION: R += fmaxf(P[off], 0.0f); break;     // d - r, |d| - r >= d - max(r,0)
+      case RM_OP_AFFINE_PUSH:
+        if (sp >= kDepth) { overflow = true; break; }
+        st[sp].n = -1; st[sp].off = off; ++sp;
+        break;
+      case RM_OP_AFFINE_POP: {   // child frame -> parent frame: p_local = rot(p - t, conj(q))
+        --sp;
+        const float* a = P + st[sp].off;
+        float w4 = a[3];
+        V3 qv = mk3(a[4], a[5], a[6]);
+        float s2 = ((w4 * w4 + qv.x * qv.x) + qv.y * qv.y) + qv.z * qv.z;
+        if (!(fabsf(s2 - 1.0f) <= 1e-5f)) { R = inf; break; }          // only (near-)unit quaternions are isometries
+        V3 c = qrot(mk3(cx, cy, cz), w4, qv);                          // inverse of the conjugate rotation
+        cx = c.x + a[0]; cy = c.y + a[1]; cz = c.z + a[2];
+        R = R * 1.0001f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+      } break;
+      case RM_OP_UNION_BEGIN: case RM_OP_SMOOTH_BEGIN:
+        if (sp >= kDepth) { overflow = true; break; }
+        st[sp].n = 0; st[sp].R = 0.0f; st[sp].cx = st[sp].cy = st[sp].cz = 0.0f; ++sp;
+        break;
+      case RM_OP_FOLD_MIN: case RM_OP_FOLD_LSE: {
+        BoundFrame& f = st[sp - 1];
+        if (f.n == 0) { f.cx = cx; f.cy = cy; f.cz = cz; f.R = R; }
+        else {
+          float dx = cx - f.cx, dy = cy - f.cy, dz = cz - f.cz;
+          f.R = fmaxf(f.R, R + sqrtf(dx * dx + dy * dy + dz * dz));   // inf propagates
+        }
+        f.n += 1;
+      } break;
+      case RM_OP_UNION_END: --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; break;
+      case RM_OP_SMOOTH_END: {   // -lse(-k d)/k >= min d - log(n)/k  for k > 0
+        --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R;
+        float k = P[off];
+        R = (k > 0.0f) ? R + logf((float)st[sp].n) / k : inf;
+      } break;
+      default: break;            // nested CULL_MIN: no effect on the bound
+    }
+  }
+  if (overflow || !(R == R)) R = inf;
+  out[0] = cx; out[1] = cy; out[2] = cz; out[3] = R;
+}
+
+// Derived constants of one instruction (capsule AB and AB/|AB|^2, primitives.py:52-54; bounding sphere
+// of a cullable union child), computed from the staged parameters.
+template <class GetIns>
+RM_DEV void derive_line_constants(GetIns ins, int pc, float* s_params) {
+  const int4 w = ins(pc);
+  if (w.x == RM_OP_LINE) {
+    const float* a = s_params + w.y;
+    float abx = a[3] - a[0], aby = a[4] - a[1], abz = a[5] - a[2];
+    float len2 = (abx * abx + aby * aby) + abz * abz;  // AB.pow(2).sum(-1)
+    float* dst = s_params + w.z;
+    dst[0] = abx; dst[1] = aby; dst[2] = abz;
+    dst[3] = abx / len2; dst[4] = aby / len2; dst[5] = abz / len2;
+  }
+}
+
+// all derived constants of a program; call with every thread of the block (contains barriers)
+template <class GetIns>
+RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
+  __shared__ BoundFrame s_bound_stack[kBoundDepth];
+  for (int i = threadIdx.x; i < n_instr; i += blockDim.x) derive_line_constants(ins, i, s_params);
+  if (threadIdx.x == 0) {     // bounding spheres: few, tiny, one after the other on one thread
+    for (int pc = 0; pc < n_instr; ++pc) {
+      const int4 w = ins(pc);
+      if (w.x == RM_OP_CULL_MIN) {
+        float* out = s_params + w.z;
+        subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), out, s_bound_stack);  // child without its FOLD
+        // cull_min_test wants  0.9999 dist - R - 1e-4 ((1 + dist) + R) >= acc,  i.e.  0.9998 dist - K >= acc
+        float K = (out[3] * 1.0001f + 1e-4f) * 1.000001f;
+        out[3] = K < __builtin_inff() ? K : __builtin_nanf("");
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// LDS staging of the scene block: raw parameters, then derived constants.
 RM_DEV void stage_scene(const RmScene& sc, float* s_params, int4* s_prog) {
   for (int i = threadIdx.x; i < sc.n_params; i += blockDim.x) s_params[i] = sc.params[i];
   const int4* gprog = reinterpret_cast<const int4*>(sc.program);
   for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) s_prog[i] = gprog[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) {
-    int4 w = s_prog[i];
-    if (w.x == RM_OP_LINE) {
-      const float* a = s_params + w.y;
-      float abx = a[3] - a[0], aby = a[4] - a[1], abz = a[5] - a[2];
-      float len2 = (abx * abx + aby * aby) + abz * abz;  // AB.pow(2).sum(-1)
-      float* dst = s_params + w.z;
-      dst[0] = abx; dst[1] = aby; dst[2] = abz;
-      dst[3] = abx / len2; dst[4] = aby / len2; dst[5] = abz / len2;
-    }
-  }
-  __syncthreads();
+  auto ins = [s_prog](int pc) { return s_prog[pc]; };
+  derive_constants(ins, sc.n_instr, s_params);
 }
 
 // --------------------------------------------------------------------------
@@ -570,9 +732,14 @@ RM_DEV void normals_from_taps(const Tetra& T, float f0, float f1, float f2, floa
 template <class SceneT>
 RM_DEV void eval_taps(const SceneT& sc, const Tetra& T, V3 p, float& f0, float& f1, float& f2, float& f3) {
   f0 = f1 = f2 = f3 = 0.0f;
+  // offsets as scalars: selecting among array elements makes LLVM spill the array to scratch and index it
+  const float ax = T.o[0].x, ay = T.o[0].y, az = T.o[0].z, bx = T.o[1].x, by = T.o[1].y, bz = T.o[1].z;
+  const float cx = T.o[2].x, cy = T.o[2].y, cz = T.o[2].z, dx = T.o[3].x, dy = T.o[3].y, dz = T.o[3].z;
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
-    const V3 ok = (k == 0) ? T.o[0] : ((k == 1) ? T.o[1] : ((k == 2) ? T.o[2] : T.o[3]));
+    const V3 ok = mk3((k == 0) ? ax : ((k == 1) ? bx : ((k == 2) ? cx : dx)),
+                      (k == 0) ? ay : ((k == 1) ? by : ((k == 2) ? cy : dy)),
+                      (k == 0) ? az : ((k == 1) ? bz : ((k == 2) ? cz : dz)));
     const float fk = sc.eval(p + ok);
     f0 = (k == 0) ? fk : f0; f1 = (k == 1) ? fk : f1; f2 = (k == 2) ? fk : f2; f3 = (k == 3) ? fk : f3;
   }

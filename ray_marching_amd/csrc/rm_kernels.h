@@ -74,19 +74,8 @@ struct StaticCfg {
     float* s_params = smem;
     for (int i = threadIdx.x; i < Code::n_params; i += blockDim.x) s_params[i] = sc.params[i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < Code::n; ++i) {
-        if (Code::code[i].op == RM_OP_LINE) {
-          const float* a = s_params + Code::code[i].off;
-          float abx = a[3] - a[0], aby = a[4] - a[1], abz = a[5] - a[2];
-          float len2 = (abx * abx + aby * aby) + abz * abz;
-          float* dst = s_params + Code::code[i].a0;
-          dst[0] = abx; dst[1] = aby; dst[2] = abz;
-          dst[3] = abx / len2; dst[4] = aby / len2; dst[5] = abz / len2;
-        }
-      }
-    }
-    __syncthreads();
+    auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
+    derive_constants(ins, Code::n, s_params);
     SceneT s;
     if constexpr (kRegParams) s.P.load(s_params); else s.P.p = s_params;
     s.st = &store;
@@ -381,9 +370,13 @@ RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float 
   }
   // one rolled loop over the four taps: a single inlined VJP body instead of four (the backward frame
   // kernel drops from 185 to fewer VGPRs and a quarter of the code)
+  const float ax = T.o[0].x, ay = T.o[0].y, az = T.o[0].z, bx = T.o[1].x, by = T.o[1].y, bz = T.o[1].z;
+  const float cx = T.o[2].x, cy = T.o[2].y, cz = T.o[2].z, dx = T.o[3].x, dy = T.o[3].y, dz = T.o[3].z;
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
-    const V3 ok = (k == 0) ? T.o[0] : ((k == 1) ? T.o[1] : ((k == 2) ? T.o[2] : T.o[3]));
+    const V3 ok = mk3((k == 0) ? ax : ((k == 1) ? bx : ((k == 2) ? cx : dx)),
+                      (k == 0) ? ay : ((k == 1) ? by : ((k == 2) ? cy : dy)),
+                      (k == 0) ? az : ((k == 1) ? bz : ((k == 2) ? cz : dz)));
     const float gk = (k == 0) ? g0 : ((k == 1) ? g1 : ((k == 2) ? g2 : g3));
     gp = gp + sc.vjp(p + ok, gk);
   }

@@ -669,6 +669,61 @@ def test_random_scene_trees_vs_oracle(seed):
         assert H.report("normals", n_got, n_ref)[0] == 0.0
 
 
+@pytest.mark.parametrize("case", ["scene2", "many32"] + [f"tree{i}" for i in (4, 11, 13, 14, 17, 18, 21)])
+def test_union_culling_changes_no_bit(case, monkeypatch):
+    """CULL_MIN (bounding-sphere skip of min-union children) is an exact optimisation:
+    the same scene compiled with RM_CULL=0 and with culling gives identical values, identical
+    point gradients and identical parameter gradients, and identical frames."""
+    from ray_marching_amd import _abi
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene, make_test_scene2
+    monkeypatch.setenv("RM_SPECIALIZE", "off")          # same (interpreter) kernels on both sides
+    gen = torch.Generator().manual_seed(77)
+    pts = torch.cat([torch.rand(4096, 3, generator=gen) * 8 - 4,          # far from the objects: culls fire
+                     torch.rand(4096, 3, generator=gen) * 2 - 1]).to(DEV)   # among them: they do not
+    wts = torch.randn(8192, 1, generator=gen).to(DEV)
+
+    def make():
+        if case == "scene2":
+            return make_test_scene2()
+        if case == "many32":
+            return make_many_primitive_scene(32)
+        g = torch.Generator().manual_seed(1000 + int(case[4:]))
+        return H.spec_to_module(O.map_spec(H.random_spec(g), lambda x: x.clone().float()))
+
+    res, n_cull = {}, {}
+    monkeypatch.setenv("RM_CULL_MIN_COST", "40" if case in ("scene2", "many32") else "0")   # trees: cull everything boundable
+    for cull in ("0", "1"):
+        monkeypatch.setenv("RM_CULL", cull)
+        module = make().to(DEV)
+        cs = compiled_for(module)
+        n_cull[cull] = int((cs.program.reshape(-1, 4)[:, 0] == _abi.OP_CULL_MIN).sum())
+        p = pts.clone().requires_grad_(True)
+        d = module(p)
+        (d * wts).sum().backward()
+        loop = H.make_loop(module, 40, 72)
+        q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV)
+        with torch.no_grad():
+            frames = [loop(q, t, m, 1, 48) for m in (0, 4, 5)]
+        for prm in module.parameters():
+            prm.grad = None
+        loop(q, t, 0, 1, 24).pow(2).mean().backward()
+        res[cull] = dict(d=d.detach(), gp=p.grad, frames=frames,
+                         gw=[None if x.grad is None else x.grad.clone() for x in module.parameters()])
+    assert n_cull["0"] == 0
+    assert n_cull["1"] > 0, "every case here is expected to carry CULL_MIN instructions"
+    a, b = res["0"], res["1"]
+    same = lambda x, y: torch.equal(torch.nan_to_num(x, nan=1234.5), torch.nan_to_num(y, nan=1234.5)) \
+        and torch.equal(x.isnan(), y.isnan())
+    assert same(a["d"], b["d"]) and same(a["gp"], b["gp"])
+    for x, y in zip(a["frames"], b["frames"]):
+        assert same(x, y)
+    for x, y in zip(a["gw"], b["gw"]):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert same(x, y)
+
+
 def test_fast_precision_is_within_tolerance_of_the_reference():
     """Opt-in precision="fast" (1-ulp v_sqrt_f32, reciprocal normalise, FMA contraction; still fp32).
     Not bit-exact by construction and NOT the product default: >= 99.8 % of pixel values stay within 1e-5

@@ -87,7 +87,7 @@ def test_compiler_lowers_reference_scenes():
     assert cs2.leaf_names == ["sdfs.0.radius", "sdfs.0.sdf.halfsides", "sdfs.1.sdfs.0.radius",
                               "sdfs.1.sdfs.1.radius1", "sdfs.1.sdfs.1.radius2", "sdfs.1.sdfs.2.start",
                               "sdfs.1.sdfs.2.end", "sdfs.1.sdfs.2.radius"]
-    assert (cs2.n_params, cs2.n_derived, cs2.n_slots) == (14, 6, 6)
+    assert (cs2.n_params, cs2.n_derived, cs2.n_slots) == (14, 10, 6)       # 6 capsule constants + 1 bounding sphere
     assert cs2.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test2())]
     cs1 = compile_scene(R.make_test_scene())
     assert cs1.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test1())]
@@ -182,7 +182,7 @@ def test_specialisation_codegen_is_deterministic():
     a, b = compile_scene(make_test_scene2()), compile_scene(make_test_scene2())
     assert specialize.scene_hash(a) == specialize.scene_hash(b)
     hdr = specialize.code_header(a)
-    assert "static constexpr int n = 14" in hdr and hdr.count("{") == 16
+    assert "static constexpr int n = 15" in hdr and hdr.count("{") == 17      # 14 node instructions + 1 CULL_MIN
     assert specialize.static_backward(a)
     from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
     assert not specialize.static_backward(compile_scene(make_many_primitive_scene(32)))
