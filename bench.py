@@ -172,8 +172,37 @@ def backward_probe(dev):
         if it > 0:
             fwd += e0.elapsed_time(e1)
             bwd += e1.elapsed_time(e2)
-    return {"config": "closed make_test_scene 512x512x64, lambertian MSE, 40 parameters",
-            "fwd_ms": fwd / reps, "bwd_ms": bwd / reps, "fwd_bwd_ms": (fwd + bwd) / reps}
+    out = {"config": "closed make_test_scene 512x512x64, lambertian MSE, 40 parameters",
+           "fwd_ms": fwd / reps, "bwd_ms": bwd / reps, "fwd_bwd_ms": (fwd + bwd) / reps}
+    # the same forward + backward captured once in a HIP graph (torch.cuda.graph) and replayed: the eager
+    # figure above is mostly host time between ~25 small launches, the replay is GPU time
+    params = list(scene.parameters())
+
+    def step():
+        (loop(q, t, 0, 1, 64)[..., :1] - target).pow(2).mean().backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            for p in params:
+                p.grad = None
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    graph.replay()
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        graph.replay()
+    torch.cuda.synchronize()
+    out["graph_fwd_bwd_ms"] = (time.perf_counter() - t0) / n * 1e3
+    return out
 
 
 def main():

@@ -61,8 +61,8 @@ enum {
   RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count */
   RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
   RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
-  RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: aux0 = derived offset of its bounding sphere
-                              {cx,cy,cz,R}; aux1 = (n << 8) | slot, n = instructions up to and including the
+  RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: aux0 = derived offset of its bound, 5 floats
+                              {cx,cy,cz,K,slope} written by the kernels at staging time; aux1 = (n << 8) | slot, n = instructions up to and including the
                               child's FOLD_MIN (whose aux1 = n).  Skips the child when it cannot lower the
                               running minimum for any ray of the wave (exact) */
   RM_OP__COUNT = 18

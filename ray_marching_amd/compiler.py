@@ -149,6 +149,7 @@ class _Emitter:
         self.cull = os.environ.get("RM_CULL", "1") != "0"    # RM_CULL=0: no CULL_MIN instructions (A/B tests)
         # RM_CULL_MIN_COST=0: a cull test in front of every boundable child, however cheap (stress tests)
         self.cull_min_cost = int(os.environ.get("RM_CULL_MIN_COST", _CULL_MIN_CHILD_COST))
+        self.cull_reorder = os.environ.get("RM_CULL_REORDER", "1") != "0"
 
     def off(self, *params):
         """Offset of the first parameter; the rest must follow contiguously."""
@@ -206,14 +207,23 @@ def _emit(node, em: _Emitter, n_params: int):
         koff = em.off(node.blend_k) if smooth else 0
         em.ins(A.OP_SMOOTH_BEGIN if smooth else A.OP_UNION_BEGIN)
         em.push(_STACK_SMOOTH if smooth else _STACK_UNION)
-        for i, child in enumerate(kids):
-            # exact culling of min-union children (never the first: nothing to compare with yet)
+        # Exact culling of min-union children.  min() does not care about the order its operands arrive in,
+        # and the reverse pass finds the winner from the tape slots, which stay in the reference's child
+        # order (ties -> first child); so the children may be EVALUATED in any order.  Children that cannot
+        # be culled (cheap, or without a bounding sphere: the room shell, planes) go first, so that the
+        # running minimum is already small when the expensive, boundable ones are tested against it.
+        cullable = [(not smooth and em.cull and base + i < 64 and _cost(child) >= em.cull_min_cost
+                     and _boundable(child)) for i, child in enumerate(kids)]
+        order = list(range(len(kids)))
+        if em.cull_reorder:
+            order = [i for i in order if not cullable[i]] + [i for i in order if cullable[i]]
+        for pos, i in enumerate(order):
+            child = kids[i]
             cull_at = None
-            if (not smooth and i > 0 and base + i < 64 and em.cull and _cost(child) >= em.cull_min_cost
-                    and _boundable(child)):
+            if cullable[i] and pos > 0:       # never the first one evaluated: nothing to compare with yet
                 cull_at = len(em.code)
                 em.ins(A.OP_CULL_MIN, 0, n_params + em.n_derived, 0)      # aux1 patched below
-                em.n_derived += 4
+                em.n_derived += 5      # {cx, cy, cz, K, slope}, filled in on the device
             _emit(child, em, n_params)
             if cull_at is not None:
                 skip = len(em.code) - cull_at

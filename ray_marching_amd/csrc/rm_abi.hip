@@ -438,7 +438,7 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
         break;
       case RM_OP_CULL_MIN: {
         const int skip = a1 >> 8, slot = a1 & 255;
-        if (a0 < n_params || a0 + 4 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: bound out of range", i);
+        if (a0 < n_params || a0 + 5 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: bound out of range", i);
         if (skip < 2 || i + skip >= n_instr || slot >= 64 || slot >= n_slots ||
             host_program[4 * (i + skip)] != RM_OP_FOLD_MIN || host_program[4 * (i + skip) + 2] != slot ||
             host_program[4 * (i + skip) + 3] != skip)

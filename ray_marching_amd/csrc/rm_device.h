@@ -153,8 +153,8 @@ struct Fwd {
 };
 
 // Exact culling of a min-union child (RM_OP_CULL_MIN).  The derived block holds a bounding sphere
-// (centre c, radius R; R = +inf when the subtree has none) of the child's surface in the union's frame,
-// computed from the live parameters at staging time, so child(p) >= |p - c| - R.  If that lower bound --
+// (centre c, radius R; R = +inf when the subtree has none) of the child's surface in the union's frame and
+// a slope sigma <= 1, computed from the live parameters at staging time, so child(p) >= sigma |p - c| - R.  If that lower bound --
 // taken with a safety margin far above fp32 rounding -- is >= the running minimum `acc` of the children
 // evaluated so far for ALL 64 rays, the child cannot lower the minimum and cannot win a tie (ties go to
 // the FIRST child), so skipping it leaves value, winner and gradients bit-identical.
@@ -162,9 +162,10 @@ template <class S, class PT>
 RM_DEV bool cull_min_test(const S& s, const PT& P, int a0) {
   V3 c = P.v3(a0);
   float K = P[a0 + 3];               // 1.0001 R + 1e-4, folded at staging (derive_constants)
+  float slope = P[a0 + 4];           // sigma - 2e-4; sigma < 1 only under un-normalised affine quaternions
   V3 d = s.p - c;
   float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
-  return __all(__builtin_fmaf(dist, 0.9998f, -K) >= s.acc);   // NaN anywhere (K is NaN for an unbounded child): false
+  return __all(__builtin_fmaf(dist, slope, -K) >= s.acc);   // NaN anywhere (K is NaN for an unbounded child): false
 }
 
 template <class S, class PT>
@@ -558,78 +559,109 @@ struct Scene {
 // parameters).  Runs once per block on one thread, from the parameters already staged in LDS.
 struct BoundFrame {
   float cx, cy, cz, R;   // union frames: enclosing sphere of the children folded so far
+  float slope;           // union frames: smallest slope among them
   int n;                 // children folded; -1 for an affine frame
   int off;               // affine frame: parameter offset
 };
 
 constexpr int kBoundDepth = 12;
 
+// Bound of the subtree [begin, end):  subtree(p) >= slope |p - c| - R  for every p, with 0.5 < slope <= 1.
+//   out = {cx, cy, cz, R, slope};  R = +inf when no finite bound is known.
+// slope < 1 comes from affine nodes whose quaternion is not unit: the reference applies
+// V + w t + qv x t, t = 2 qv x V (quaternion.py:55-72) without normalising, which for q = |q| u is the
+// normal matrix M = (1 - s) I + s R_u, s = |q|^2, whose smallest singular value is min(1, 2 s - 1).
 template <class GetIns>
-RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float* out /*[4]*/, BoundFrame* st) {
+RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float* out /*[5]*/, BoundFrame* st) {
   constexpr int kDepth = kBoundDepth;
   int sp = 0;
-  float cx = 0.0f, cy = 0.0f, cz = 0.0f, R = __builtin_inff();
+  float cx = 0.0f, cy = 0.0f, cz = 0.0f, R = __builtin_inff(), slope = 1.0f;
   const float inf = __builtin_inff();
   bool overflow = false;
   for (int pc = begin; pc < end && !overflow; ++pc) {
     const int4 w = ins(pc);
     const int op = w.x, off = w.y;
     switch (op) {
-      case RM_OP_SPHERE: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_SPHERE: cx = cy = cz = 0.0f; slope = 1.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
       case RM_OP_BOX: {
         float hx = P[off], hy = P[off + 1], hz = P[off + 2];
-        cx = cy = cz = 0.0f;
+        cx = cy = cz = 0.0f; slope = 1.0f;
         R = (hx >= 0.0f && hy >= 0.0f && hz >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) : inf;
       } break;
-      case RM_OP_PLANE: R = inf; break;
-      case RM_OP_LINE: {
+      case RM_OP_PLANE: slope = 1.0f; R = inf; break;
+      case RM_OP_LINE: {   // capsule: sphere around the midpoint of AB
         const float* a = P + off;
-        float ls = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), le = sqrtf(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
-        cx = cy = cz = 0.0f;
-        R = (a[6] >= 0.0f) ? fmaxf(ls, le) + a[6] : inf;
+        cx = 0.5f * (a[0] + a[3]); cy = 0.5f * (a[1] + a[4]); cz = 0.5f * (a[2] + a[5]);
+        float hx = 0.5f * (a[3] - a[0]), hy = 0.5f * (a[4] - a[1]), hz = 0.5f * (a[5] - a[2]);
+        slope = 1.0f;
+        R = (a[6] >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) * 1.00001f + a[6] : inf;
       } break;
-      case RM_OP_DISK: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
-      case RM_OP_TORUS: cx = cy = cz = 0.0f; R = (P[off] >= 0.0f && P[off + 1] >= 0.0f) ? P[off] + P[off + 1] : inf; break;
+      case RM_OP_DISK: cx = cy = cz = 0.0f; slope = 1.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_TORUS:
+        cx = cy = cz = 0.0f; slope = 1.0f;
+        R = (P[off] >= 0.0f && P[off + 1] >= 0.0f) ? P[off] + P[off + 1] : inf;
+        break;
       case RM_OP_ROUND: case RM_OP_ONION: R += fmaxf(P[off], 0.0f); break;     // d - r, |d| - r >= d - max(r,0)
       case RM_OP_AFFINE_PUSH:
         if (sp >= kDepth) { overflow = true; break; }
         st[sp].n = -1; st[sp].off = off; ++sp;
         break;
-      case RM_OP_AFFINE_POP: {   // child frame -> parent frame: p_local = rot(p - t, conj(q))
+      case RM_OP_AFFINE_POP: {   // child frame -> parent frame: y = M (p - t), M = qrot(., conj(q))
         --sp;
         const float* a = P + st[sp].off;
         float w4 = a[3];
         V3 qv = mk3(a[4], a[5], a[6]);
         float s2 = ((w4 * w4 + qv.x * qv.x) + qv.y * qv.y) + qv.z * qv.z;
-        if (!(fabsf(s2 - 1.0f) <= 1e-5f)) { R = inf; break; }          // only (near-)unit quaternions are isometries
-        V3 c = qrot(mk3(cx, cy, cz), w4, qv);                          // inverse of the conjugate rotation
-        cx = c.x + a[0]; cy = c.y + a[1]; cz = c.z + a[2];
-        R = R * 1.0001f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+        float sigma = fminf(1.0f, 2.0f * s2 - 1.0f) - 1e-5f;           // smallest singular value of M, rounded down
+        if (!(sigma > 0.5f) || !(s2 < 4.0f)) { R = inf; break; }
+        // child(y) >= slope |y - c| - R.  Take c' = M'(c) (M' = qrot(., q); exactly M^-1 only for unit q) and
+        // measure the miss e = |M c' - c|:  |y - c| >= |M (p - t - c')| - e >= sigma |p - (t + c')| - e.
+        V3 c0 = mk3(cx, cy, cz);
+        V3 c1 = qrot(c0, w4, qv);
+        V3 back = qrot(c1, w4, neg(qv)) - c0;
+        float e = sqrtf((back.x * back.x + back.y * back.y) + back.z * back.z);
+        cx = c1.x + a[0]; cy = c1.y + a[1]; cz = c1.z + a[2];
+        R = (R + e) * 1.0001f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+        slope = slope * sigma;
       } break;
       case RM_OP_UNION_BEGIN: case RM_OP_SMOOTH_BEGIN:
         if (sp >= kDepth) { overflow = true; break; }
-        st[sp].n = 0; st[sp].R = 0.0f; st[sp].cx = st[sp].cy = st[sp].cz = 0.0f; ++sp;
+        st[sp].n = 0; st[sp].R = 0.0f; st[sp].slope = 1.0f; st[sp].cx = st[sp].cy = st[sp].cz = 0.0f; ++sp;
         break;
       case RM_OP_FOLD_MIN: case RM_OP_FOLD_LSE: {
+        // child_i(p) >= slope_i |p - c_i| - R_i >= slope (|p - c| - |c - c_i|) - R_i  with slope = min slope_i <= 1,
+        // so any sphere (c, R) that encloses all the spheres (c_i, R_i) bounds the min: smallest sphere around two.
         BoundFrame& f = st[sp - 1];
-        if (f.n == 0) { f.cx = cx; f.cy = cy; f.cz = cz; f.R = R; }
+        if (f.n == 0) { f.cx = cx; f.cy = cy; f.cz = cz; f.R = R; f.slope = slope; }
         else {
           float dx = cx - f.cx, dy = cy - f.cy, dz = cz - f.cz;
-          f.R = fmaxf(f.R, R + sqrtf(dx * dx + dy * dy + dz * dz));   // inf propagates
+          float d = sqrtf(dx * dx + dy * dy + dz * dz) * 1.00001f;
+          if (!(f.R < inf) || !(R < inf)) { f.R = inf; }
+          else if (d + R <= f.R) { /* already inside */ }
+          else if (d + f.R <= R) { f.cx = cx; f.cy = cy; f.cz = cz; f.R = R; }
+          else {
+            float Rn = 0.5f * ((d + f.R) + R);
+            float tt = (Rn - f.R) / d;                     // d > 0 here
+            f.cx += tt * dx; f.cy += tt * dy; f.cz += tt * dz;
+            f.R = Rn * 1.00001f + 1e-6f * (fabsf(f.cx) + fabsf(f.cy) + fabsf(f.cz));
+          }
+          f.slope = fminf(f.slope, slope);
         }
         f.n += 1;
       } break;
-      case RM_OP_UNION_END: --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; break;
+      case RM_OP_UNION_END:
+        --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; slope = st[sp].slope;
+        break;
       case RM_OP_SMOOTH_END: {   // -lse(-k d)/k >= min d - log(n)/k  for k > 0
-        --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R;
+        --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; slope = st[sp].slope;
         float k = P[off];
         R = (k > 0.0f) ? R + logf((float)st[sp].n) / k : inf;
       } break;
       default: break;            // nested CULL_MIN: no effect on the bound
     }
   }
-  if (overflow || !(R == R)) R = inf;
-  out[0] = cx; out[1] = cy; out[2] = cz; out[3] = R;
+  if (overflow || !(R == R) || !(slope > 0.5f)) R = inf;
+  out[0] = cx; out[1] = cy; out[2] = cz; out[3] = R; out[4] = slope;
 }
 
 // Derived constants of one instruction (capsule AB and AB/|AB|^2, primitives.py:52-54; bounding sphere
@@ -658,9 +690,11 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
       if (w.x == RM_OP_CULL_MIN) {
         float* out = s_params + w.z;
         subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), out, s_bound_stack);  // child without its FOLD
-        // cull_min_test wants  0.9999 dist - R - 1e-4 ((1 + dist) + R) >= acc,  i.e.  0.9998 dist - K >= acc
+        // cull_min_test:  (slope - 2e-4) dist - K >= acc  with  K = 1.0001 R + 1e-4 : the bound with a margin of
+        // 1e-4 (1 + 2 dist + R), three orders of magnitude above the fp32 rounding of the child's own value
         float K = (out[3] * 1.0001f + 1e-4f) * 1.000001f;
         out[3] = K < __builtin_inff() ? K : __builtin_nanf("");
+        out[4] = out[4] - 2e-4f;
       }
     }
   }

@@ -669,14 +669,15 @@ def test_random_scene_trees_vs_oracle(seed):
         assert H.report("normals", n_got, n_ref)[0] == 0.0
 
 
-@pytest.mark.parametrize("case", ["scene2", "many32"] + [f"tree{i}" for i in (4, 11, 13, 14, 17, 18, 21)])
+@pytest.mark.parametrize("case", ["scene2", "scene1c", "many32"] + [f"tree{i}" for i in (4, 11, 13, 14, 17, 18, 21)])
 def test_union_culling_changes_no_bit(case, monkeypatch):
     """CULL_MIN (bounding-sphere skip of min-union children) is an exact optimisation:
     the same scene compiled with RM_CULL=0 and with culling gives identical values, identical
     point gradients and identical parameter gradients, and identical frames."""
     from ray_marching_amd import _abi
     from ray_marching_amd.compiler import compiled_for
-    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene, make_test_scene2
+    from ray_marching_amd.scene.scene_registry import (make_closed_test_scene, make_many_primitive_scene,
+                                                       make_test_scene2)
     monkeypatch.setenv("RM_SPECIALIZE", "off")          # same (interpreter) kernels on both sides
     gen = torch.Generator().manual_seed(77)
     pts = torch.cat([torch.rand(4096, 3, generator=gen) * 8 - 4,          # far from the objects: culls fire
@@ -688,11 +689,13 @@ def test_union_culling_changes_no_bit(case, monkeypatch):
             return make_test_scene2()
         if case == "many32":
             return make_many_primitive_scene(32)
+        if case == "scene1c":                   # evaluation order differs from child order; |q|^2 = 1.00002
+            return make_closed_test_scene()
         g = torch.Generator().manual_seed(1000 + int(case[4:]))
         return H.spec_to_module(O.map_spec(H.random_spec(g), lambda x: x.clone().float()))
 
     res, n_cull = {}, {}
-    monkeypatch.setenv("RM_CULL_MIN_COST", "40" if case in ("scene2", "many32") else "0")   # trees: cull everything boundable
+    monkeypatch.setenv("RM_CULL_MIN_COST", "40" if not case.startswith("tree") else "0")   # trees: cull everything boundable
     for cull in ("0", "1"):
         monkeypatch.setenv("RM_CULL", cull)
         module = make().to(DEV)
@@ -722,6 +725,54 @@ def test_union_culling_changes_no_bit(case, monkeypatch):
         assert (x is None) == (y is None)
         if x is not None:
             assert same(x, y)
+
+
+def test_training_step_captured_in_a_graph_matches_eager():
+    """forward + backward of the fused frame (config 4 shape, small) recorded with torch.cuda.graph:
+    the replayed gradients equal the eager ones (up to the grouping of per-block partial sums, which
+    follows the dynamic tile schedule) and track parameter updates made between replays."""
+    from ray_marching_amd.scene.scene_registry import make_closed_test_scene
+    scene = make_closed_test_scene()
+    loop = H.make_loop(scene, 64, 64)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -1.0]], device=DEV)
+    target = torch.rand(1, 64, 64, 1, device=DEV)
+    params = list(scene.parameters())
+
+    def step():
+        loss = (loop(q, t, 0, 1, 32)[..., :1] - target).pow(2).mean()
+        loss.backward()
+        return loss
+
+    def eager():
+        for p in params:
+            p.grad = None
+        loss = step()
+        return loss.item(), [p.grad.clone() for p in params]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for p in params:
+                p.grad = None
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    for trial in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        got_loss, got = loss.item(), [p.grad.clone() for p in params]
+        want_loss, want = eager()
+        assert abs(got_loss - want_loss) <= 1e-6
+        for a, b in zip(got, want):
+            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+        with torch.no_grad():                       # move the scene; the graph reads the live parameters
+            for p in params:
+                p.add_(0.01 * torch.randn_like(p))
 
 
 def test_fast_precision_is_within_tolerance_of_the_reference():

@@ -87,7 +87,7 @@ def test_compiler_lowers_reference_scenes():
     assert cs2.leaf_names == ["sdfs.0.radius", "sdfs.0.sdf.halfsides", "sdfs.1.sdfs.0.radius",
                               "sdfs.1.sdfs.1.radius1", "sdfs.1.sdfs.1.radius2", "sdfs.1.sdfs.2.start",
                               "sdfs.1.sdfs.2.end", "sdfs.1.sdfs.2.radius"]
-    assert (cs2.n_params, cs2.n_derived, cs2.n_slots) == (14, 10, 6)       # 6 capsule constants + 1 bounding sphere
+    assert (cs2.n_params, cs2.n_derived, cs2.n_slots) == (14, 11, 6)       # 6 capsule constants + 1 cull bound {c, K, slope}
     assert cs2.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test2())]
     cs1 = compile_scene(R.make_test_scene())
     assert cs1.leaf_names == [n for n, _ in O.spec_parameters(O.scene_test1())]
