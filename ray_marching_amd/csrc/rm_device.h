@@ -131,7 +131,11 @@ struct RegParams {
   float v[N > 0 ? N : 1];
   RM_DEV void load(const float* lds) {
 #pragma unroll
+#if defined(RM_VGPR_PARAMS)   // experiment knob: VGPR-resident copies (measured: no gain, +20 VGPRs)
+    for (int i = 0; i < N; ++i) v[i] = lds[i];
+#else
     for (int i = 0; i < N; ++i) v[i] = uniform_f(lds[i]);
+#endif
   }
   RM_DEV float operator[](int i) const { return v[i]; }
   RM_DEV V3 v3(int i) const { return V3{v[i], v[i + 1], v[i + 2]}; }

@@ -196,14 +196,17 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
                 int64_t ray, bool live, int& nexec) {
   V3 snap = p;          // remembered iterate p_s (per lane)
   int snap_step = 0;    // s            (wave-uniform: every lane refreshes at the same steps)
-  int next_snap = 1;    // refresh the snapshot when the step index reaches this (1, 2, 4, ...)
+  int next_snap = 2;    // refresh the snapshot when the step index reaches this (2, 4, 8, ...)
   int lambda = 0;       // cycle length of this ray, 0 = not known yet
   nexec = steps;
   for (int i = 0; i < steps; ++i) {
     if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
     float f = scene.eval(p);
     V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
-    if (early) {
+    if (early && (i & 1)) {
+      // Looked at after every SECOND step only (i odd, so the candidate periods i + 1 - s are even: a
+      // multiple of the true period serves just as well, and a fixed point is a cycle of any length):
+      // the ~16 compare/select instructions are ~7 % of a step, a wave leaves at most one step later.
       // branch-free per-lane bookkeeping (selects, no exec-mask juggling)
       const bool fixed = same_bits(pn, p);
       const bool cyc = !traj && same_bits(pn, snap);

@@ -762,10 +762,11 @@ def test_training_step_captured_in_a_graph_matches_eager():
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         loss = step()
+    captured = [p.grad for p in params]         # the replay writes here, whatever p.grad points at later
     for trial in range(2):
         graph.replay()
         torch.cuda.synchronize()
-        got_loss, got = loss.item(), [p.grad.clone() for p in params]
+        got_loss, got = loss.item(), [g.clone() for g in captured]
         want_loss, want = eager()
         assert abs(got_loss - want_loss) <= 1e-6
         for a, b in zip(got, want):
