@@ -6,7 +6,6 @@ import torch
 import bench
 
 dev = torch.device("cuda:0")
-print(bench.backward_probe(dev))
 from ray_marching_amd.control import RenderLoop
 from ray_marching_amd.scene.scene_registry import make_closed_test_scene
 h = w = 512

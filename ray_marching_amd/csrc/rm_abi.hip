@@ -51,6 +51,10 @@ struct Launch {
 
 #ifdef RM_STATIC_CODE
 using G = rm::StaticCfg<RmStaticCode>;
+#ifndef RM_BWD_REG_PARAMS
+#define RM_BWD_REG_PARAMS 64
+#endif
+using GB = rm::StaticCfg<RmStaticCode, RM_BWD_REG_PARAMS>;   // backward kernels: parameter floats kept in SGPRs up to this many
 // static path: parameter block + (backward) one accumulator row per wave for the block reduction
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
@@ -64,6 +68,7 @@ int check_static(const RmScene* sc) {
 }
 #else
 using G = rm::GenericCfg;
+using GB = rm::GenericCfg;
 int check_static(const RmScene*) { return RM_OK; }
 // LDS bytes of the generic path for a block of `block` threads.
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
@@ -157,9 +162,9 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
   if (int e = check_scene(scene)) return e;
   if (n <= 0 || !points || !grad_dist || !partials) return fail(RM_E_BADARG, "rm_sdf_backward: null buffer / n<=0");
   Launch L;
-  if (int e = pick_launch(rm::k_sdf_bwd<G>, *scene, true, 128, &L)) return e;
+  if (int e = pick_launch(rm::k_sdf_bwd<GB>, *scene, true, 128, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
-  rm::k_sdf_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
+  rm::k_sdf_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
   if (int e = launched("k_sdf_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
 #endif
@@ -187,9 +192,9 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
   if (n <= 0 || steps < 0 || !dirs || !grad_out || !partials || (steps > 0 && !traj))
     return fail(RM_E_BADARG, "rm_march_backward: bad args");
   Launch L;
-  if (int e = pick_launch(rm::k_march_bwd<G>, *scene, true, 128, &L)) return e;
+  if (int e = pick_launch(rm::k_march_bwd<GB>, *scene, true, 128, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
-  rm::k_march_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, dirs, traj, nexec, grad_out, grad_pos, grad_dirs,
+  rm::k_march_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, dirs, traj, nexec, grad_out, grad_pos, grad_dirs,
                                                                    partials, n, steps);
   if (int e = launched("k_march_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
@@ -217,9 +222,9 @@ int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float*
   if (int e = check_scene(scene)) return e;
   if (!tetra || n <= 0 || !coords || !partials) return fail(RM_E_BADARG, "rm_normals_backward: bad args");
   Launch L;
-  if (int e = pick_launch(rm::k_normals_bwd<G>, *scene, true, 128, &L)) return e;
+  if (int e = pick_launch(rm::k_normals_bwd<GB>, *scene, true, 128, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
-  rm::k_normals_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, grad_normals, grad_lap,
+  rm::k_normals_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, grad_normals, grad_lap,
                                                                      grad_coords, partials, n);
   if (int e = launched("k_normals_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
@@ -383,7 +388,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.grad_pos = grad_pos; a.grad_dirs = grad_dirs;
   a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
-  if (int e = pick_launch(rm::k_render_bwd<G>, *scene, true, 128, &L)) return e;
+  if (int e = pick_launch(rm::k_render_bwd<GB>, *scene, true, 128, &L)) return e;
   int64_t wave_tiles;
   {
     const int W = cam->width, rows = row_end - row_begin;
@@ -391,7 +396,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                                            : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
   int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), kMaxBlocksBwd);
-  rm::k_render_bwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  rm::k_render_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
 #endif

@@ -55,14 +55,14 @@ struct GenericCfg {
 };
 
 // Compile-time scene: Code supplies n, code[], n_params, n_derived, stack_floats, n_slots.
-template <class Code>
+template <class Code, int kRegParamLimit = 64>
 struct StaticCfg {
   static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_derived;
   using Store = RegStore<kStoreN>;
   using Prog = StaticProgram<Code>;
   // small parameter blocks ride in registers; big ones (config 5: 381 floats) stay in LDS
   static constexpr int kParamFloats = Code::n_params + Code::n_derived;
-  static constexpr bool kRegParams = kParamFloats <= 64;
+  static constexpr bool kRegParams = kParamFloats <= kRegParamLimit;
   using PT = std::conditional_t<kRegParams, RegParams<kParamFloats>, LdsParams>;
   using SceneT = Scene<Prog, Store, PT>;
   static constexpr bool kStatic = true;
@@ -265,27 +265,33 @@ __global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const float* __re
 // inside the 1e-4 gradient tolerance (tests: worst |grad error| unchanged at 1e-6 level).
 template <class SceneT>
 RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
-                        int64_t ray, int nexec, int steps, V3* gv, bool early) {
+                        int64_t ray, int nexec, int steps, bool want_gv, V3& gv, bool early) {
+  // `gv` by reference and a flag, not an optional pointer: a pointer that may be null pins the vector in
+  // scratch memory (a load + store + vmcnt(0) per step).  The iterate of the NEXT step is fetched before
+  // this step's VJP, so its HBM/L2 latency hides behind ~1000 instructions instead of stalling the wave.
+  if (steps <= 0) return lam;               // no trajectory buffer at all in that case
+  V3 p_next = (steps - 1 < nexec) ? load3(traj + 3 * (int64_t)(steps - 1) * traj_stride, ray) : p_final;
   for (int i = steps - 1; i >= 0; --i) {
     float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
     if (early) {
       float bound = 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
       if (__all(fabsf(gf) <= bound)) {
-        if (gv) {
+        if (want_gv) {
           // steps 0..i are skipped with lambda frozen: sum_i f(p_i) = (p_{i+1} - p_0).v / |v|^2
           V3 pn = (i + 1 < nexec) ? load3(traj + 3 * (int64_t)(i + 1) * traj_stride, ray) : p_final;
           V3 p0 = load3(traj, ray);
           V3 dp = pn - p0;
           float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
-          *gv = *gv + sumf * lam;
+          gv = gv + sumf * lam;
         }
         break;
       }
     }
-    V3 p = (i < nexec) ? load3(traj + 3 * (int64_t)i * traj_stride, ray) : p_final;
+    V3 p = p_next;
+    if (i > 0) p_next = (i - 1 < nexec) ? load3(traj + 3 * (int64_t)(i - 1) * traj_stride, ray) : p_final;
     float f;
     V3 gp = scene.vjp(p, gf, &f);
-    if (gv) *gv = *gv + f * lam;
+    if (want_gv) gv = gv + f * lam;
     lam = lam + gp;
   }
   return lam;
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __re
     // so every iterate from nexec-1 on equals the last stored one.
     int ne = nexec ? nexec[ic] : steps;
     V3 pf = (ne > 0) ? load3(traj + 3 * (int64_t)(ne - 1) * n, ic) : mk3(0.0f, 0.0f, 0.0f);
-    lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs ? &gv : nullptr, false);
+    lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs != nullptr, gv, false);
     if (live) {
       if (gpos) store3(gpos, i, lam);
       if (gdirs) store3(gdirs, i, gv);
@@ -932,7 +938,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     }
     V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
     int ne = a.nexec ? a.nexec[li] : a.steps;
-    lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs ? &gv : nullptr,
+    lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
                         a.flags & RM_FLAG_EARLY_OUT);
     if (live && a.grad_pos) store3(a.grad_pos, li, lam);
     if (live && a.grad_dirs) store3(a.grad_dirs, li, gv);
