@@ -154,7 +154,12 @@ struct Fwd {
   Store* st;
   bool record; // record every fold/onion input (needed by the reverse sweep)
   unsigned long long culled;  // wave-uniform: bit s set = the union child folding into tape slot s was skipped
+  // Tracked cull sites (StaticProgram, outermost frame, first kCullTracked of them): per-lane bounds
+  // lo <= lhs <= hi on the site's test value lhs = slope |p - c| - K at THIS point, carried over from its
+  // last full test through the known movement of the point (Scene::eval_near).  NaN = unknown.
+  float cull_lo[2], cull_hi[2];
 };
+constexpr int kCullTracked = 2;
 
 // Exact culling of a min-union child (RM_OP_CULL_MIN).  The derived block holds a bounding sphere
 // (centre c, radius R; R = +inf when the subtree has none) of the child's surface in the union's frame and
@@ -163,13 +168,30 @@ struct Fwd {
 // evaluated so far for ALL 64 rays, the child cannot lower the minimum and cannot win a tie (ties go to
 // the FIRST child), so skipping it leaves value, winner and gradients bit-identical.
 template <class S, class PT>
-RM_DEV bool cull_min_test(const S& s, const PT& P, int a0) {
+RM_DEV float cull_min_lhs(const S& s, const PT& P, int a0) {
   V3 c = P.v3(a0);
-  float K = P[a0 + 3];               // 1.0001 R + 1e-4, folded at staging (derive_constants)
+  float K = P[a0 + 3];               // 1.0001 R + 1e-4 + 1e-5 |c|_1, folded at staging (derive_constants)
   float slope = P[a0 + 4];           // sigma - 2e-4; sigma < 1 only under un-normalised affine quaternions
   V3 d = s.p - c;
   float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
-  return __all(__builtin_fmaf(dist, slope, -K) >= s.acc);   // NaN anywhere (K is NaN for an unbounded child): false
+  return __builtin_fmaf(dist, slope, -K);
+}
+template <class S, class PT>
+RM_DEV bool cull_min_test(const S& s, const PT& P, int a0) {
+  return __all(cull_min_lhs(s, P, a0) >= s.acc);   // NaN anywhere (K is NaN for an unbounded child): false
+}
+// The same decision for a tracked site (index T): lhs is 1-Lipschitz in p (slope <= 1), so after the point
+// has moved by at most `move` since the bounds were last refreshed, lo - move <= lhs <= hi + move (applied
+// by Scene::eval_near).  If lo >= acc for every ray the full test would pass; if hi < acc for some ray it
+// would fail; only in between are the 9 instructions of the full test spent, which also refreshes the
+// bounds.  Comparisons with NaN (unknown) are false, so an unknown bound always takes the full test.
+template <int T, class S, class PT>
+RM_DEV bool cull_min_tracked(S& s, const PT& P, int a0) {
+  if (__all(s.cull_lo[T] >= s.acc)) return true;
+  if (__any(s.cull_hi[T] < s.acc)) return false;
+  float lhs = cull_min_lhs(s, P, a0);
+  s.cull_lo[T] = lhs; s.cull_hi[T] = lhs;
+  return __all(lhs >= s.acc);
 }
 
 template <class S, class PT>
@@ -476,6 +498,17 @@ struct RuntimeProgram {
 // Compile-time program: Code::code[] is constexpr, recursion unrolls it.
 template <class Code>
 struct StaticProgram {
+  // index of the CULL_MIN at `pc` among the tracked sites (outermost frame only: inside an affine frame the
+  // local point moves by |M dp|, which an un-normalised quaternion can stretch), or -1
+  static constexpr int tracked_site(int pc) {
+    int depth = 0, k = 0;
+    for (int i = 0; i < pc; ++i) {
+      if (Code::code[i].op == RM_OP_AFFINE_PUSH) ++depth;
+      if (Code::code[i].op == RM_OP_AFFINE_POP) --depth;
+      if (Code::code[i].op == RM_OP_CULL_MIN && depth == 0) ++k;
+    }
+    return (depth == 0 && k < kCullTracked) ? k : -1;
+  }
   // executes instructions [PC, END)
   template <int PC, int END, class S, class PT>
   RM_DEV void fwd_range(S& s, const PT& P) const {
@@ -483,7 +516,10 @@ struct StaticProgram {
       constexpr Ins i = Code::code[PC];
       if constexpr (i.op == RM_OP_CULL_MIN) {
         constexpr int skip = i.a1 >> 8, slot = i.a1 & 255;
-        if (cull_min_test(s, P, i.a0)) {
+        constexpr int T = tracked_site(PC);
+        bool cull;
+        if constexpr (T >= 0) cull = cull_min_tracked<T>(s, P, i.a0); else cull = cull_min_test(s, P, i.a0);
+        if (cull) {
           if (s.record) { s.st->st(s.tape0 + slot, __builtin_inff()); s.culled |= 1ull << slot; }
         } else {
           fwd_range<PC + 1, PC + 1 + skip>(s, P);
@@ -529,19 +565,32 @@ struct Scene {
   int tape0;   // store index of tape slot 0 (= stack_floats)
   int acc0;    // store index of gradient accumulator 0 (= stack_floats + n_slots)
 
-  RM_DEV float eval(V3 p, bool record = false) const {
+  // bounds of the tracked cull sites at the point of the previous evaluation (per lane; NaN = unknown)
+  mutable float cull_lo[kCullTracked] = {__builtin_nanf(""), __builtin_nanf("")};
+  mutable float cull_hi[kCullTracked] = {__builtin_nanf(""), __builtin_nanf("")};
+
+  // f(p) where p is at most `move` away from the point of this context's previous evaluation (NaN: no
+  // such knowledge).  Identical value; the knowledge only decides which cull tests can be skipped.
+  RM_DEV float eval_near(V3 p, float move, bool record = false) const {
     Fwd<Store> s;
     s.p = p; s.d = 0.0f; s.acc = __builtin_inff(); s.sp = 0; s.tape0 = tape0; s.st = st; s.record = record;
     s.culled = 0ull;
+#pragma unroll
+    for (int k = 0; k < kCullTracked; ++k) { s.cull_lo[k] = cull_lo[k] - move; s.cull_hi[k] = cull_hi[k] + move; }
     prog.forward(s, P);
+#pragma unroll
+    for (int k = 0; k < kCullTracked; ++k) { cull_lo[k] = s.cull_lo[k]; cull_hi[k] = s.cull_hi[k]; }
     return s.d;
   }
+  RM_DEV float eval(V3 p, bool record = false) const { return eval_near(p, __builtin_nanf(""), record); }
   // VJP at point p with upstream g: returns dL/dp, adds parameter grads into the accumulators.
   // `value` (optional) receives f(p) from the recording forward pass.
   RM_DEV V3 vjp(V3 p, float g, float* value = nullptr) const {
     Fwd<Store> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
     f.culled = 0ull;
+#pragma unroll
+    for (int k = 0; k < kCullTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
     prog.forward(f, P);
     if (value) *value = f.d;
     Bwd<Store> b;
@@ -696,7 +745,8 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
         subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), out, s_bound_stack);  // child without its FOLD
         // cull_min_test:  (slope - 2e-4) dist - K >= acc  with  K = 1.0001 R + 1e-4 : the bound with a margin of
         // 1e-4 (1 + 2 dist + R), three orders of magnitude above the fp32 rounding of the child's own value
-        float K = (out[3] * 1.0001f + 1e-4f) * 1.000001f;
+        // (+ 1e-5 |c|_1: rounding drift of p over the <= 16 steps a tracked bound is carried, eval_near)
+        float K = ((out[3] * 1.0001f + 1e-4f) + 1e-5f * ((fabsf(out[0]) + fabsf(out[1])) + fabsf(out[2]))) * 1.000001f;
         out[3] = K < __builtin_inff() ? K : __builtin_nanf("");
         out[4] = out[4] - 2e-4f;
       }

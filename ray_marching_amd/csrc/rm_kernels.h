@@ -199,9 +199,15 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
   int next_snap = 2;    // refresh the snapshot when the step index reaches this (2, 4, 8, ...)
   int lambda = 0;       // cycle length of this ray, 0 = not known yet
   nexec = steps;
+  // |v| (1 + 1e-4): the point moves by |f| |v| per step, which is what lets a cull decision be carried
+  // from one step to the next (Scene::eval_near); every 16th step the knowledge is dropped, so rounding
+  // drift of p cannot accumulate beyond the slack folded into the bound (derive_constants)
+  const float vn = 1.0001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+  float move = __builtin_nanf("");
   for (int i = 0; i < steps; ++i) {
     if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
-    float f = scene.eval(p);
+    float f = scene.eval_near(p, (i & 15) ? move : __builtin_nanf(""));
+    move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
     V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
     if (early && (i & 1)) {
       // Looked at after every SECOND step only (i odd, so the candidate periods i + 1 - s are even: a

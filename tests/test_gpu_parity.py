@@ -727,6 +727,39 @@ def test_union_culling_changes_no_bit(case, monkeypatch):
             assert same(x, y)
 
 
+@pytest.mark.parametrize("case", ["scene2", "scene1c", "many32"])
+def test_tracked_culls_in_specialised_kernels_change_no_bit(case, monkeypatch):
+    """The specialised march loop carries cull decisions from step to step (Scene::eval_near: bounds on
+    the test value moved by |f||v|, refreshed every 16 steps).  Frames from those kernels equal the frames
+    of the interpreter running the same scene compiled WITHOUT any CULL_MIN, bit for bit, from cameras
+    inside the object group, far outside it, and looking along a wall."""
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import (make_closed_test_scene, make_many_primitive_scene,
+                                                       make_test_scene2)
+    make = {"scene2": make_test_scene2, "scene1c": make_closed_test_scene,
+            "many32": lambda: make_many_primitive_scene(32)}[case]
+    poses = [([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, -3.0]), ([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 1.0]),
+             ([0.9239, 0.0, 0.3827, 0.0], [4.5, -4.0, -4.5]), ([0.7071, 0.7071, 0.0, 0.0], [0.3, 4.7, 0.2])]
+    frames = {}
+    for variant in ("interp_nocull", "static_tracked"):
+        monkeypatch.setenv("RM_CULL", "0" if variant == "interp_nocull" else "1")
+        monkeypatch.setenv("RM_SPECIALIZE", "off" if variant == "interp_nocull" else "auto")
+        specialize._loaded.clear()
+        loop = H.make_loop(make(), 72, 128)
+        assert compiled_for(loop.scene).specialised == (variant == "static_tracked")
+        out = []
+        with torch.no_grad():
+            for q, t in poses:
+                qq = torch.tensor([q], device=DEV); tt = torch.tensor([t], device=DEV)
+                out += [loop(qq, tt, m, 1, 160) for m in (4, 0, 5)]
+        frames[variant] = out
+    specialize._loaded.clear()
+    for a, b in zip(frames["interp_nocull"], frames["static_tracked"]):
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        assert torch.equal(a.isnan(), b.isnan())
+
+
 def test_training_step_captured_in_a_graph_matches_eager():
     """forward + backward of the fused frame (config 4 shape, small) recorded with torch.cuda.graph:
     the replayed gradients equal the eager ones (up to the grouping of per-block partial sums, which
