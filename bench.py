@@ -288,14 +288,12 @@ def main():
 
     def one_step(step_idx, timed):
         handles = []
+        from ray_marching_amd import ops
         for j, mode in enumerate(MODES):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            # HIP events on the launch stream immediately around the k_render_fwd launch (ops.Render.run)
+            ops.kernel_event_sink = kernel_ms if timed else None
             img = loop(q, t, mode, 1, STEPS_MARCH, rows=rows)
-            if timed:
-                e1.record()
-                kernel_ms.append((e0, e1))
+            ops.kernel_event_sink = None
             if gather:
                 done = torch.cuda.Event()
                 done.record()

@@ -264,6 +264,11 @@ def camera_forward(ray_positions, ray_directions, orientation, translation):
 _GLOBAL_MODES = (1, 2, 5)
 
 
+# measurement hook (bench.py): when set to a list, Render.run appends a (start, end) pair of timing events
+# recorded on the launch stream immediately around the k_render_fwd launch
+kernel_event_sink = None
+
+
 class Render(torch.autograd.Function):
     """RenderLoop.forward as one kernel (+ the normalisation pass of modes 1, 2, 5).
 
@@ -307,11 +312,19 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(ray_positions, ray_directions)
             _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
+            sink = kernel_event_sink
+            if sink is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             _abi.check(cs.lib(False, precision).rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
                                               _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
                                               _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                               mode, degree, steps, r0, r1, flags, stream), "rm_render_forward",
                        cs.lib(False, precision))
+            if sink is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                sink.append((ev0, ev1))
             if mode in _GLOBAL_MODES:
                 if allreduce_minmax is not None:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
