@@ -114,6 +114,51 @@ def test_compiler_lowers_reference_scenes():
         assert cs.pack_params("cpu")[0].item() == pytest.approx(0.6)
 
 
+def test_compiler_cull_placement_and_evaluation_order(monkeypatch):
+    """CULL_MIN: only in front of expensive, boundable children of a min-union; children that
+    cannot be culled are EVALUATED first while tape slots keep the reference's child order (the reverse
+    pass picks the first minimal slot = torch's argmin); every variant passes rm_validate_program."""
+    import numpy as np
+    from ray_marching_amd import _abi
+    from ray_marching_amd.compiler import compile_scene
+    from ray_marching_amd.scene import scene_registry as R
+    from ray_marching_amd.scene.primitives import SDFPlane, SDFSphere
+    from ray_marching_amd.scene.transformations import SDFUnion
+
+    def rows(cs):
+        return np.asarray(cs.program).reshape(-1, 4)
+
+    def ops(cs):
+        return rows(cs)[:, 0].tolist()
+
+    # closed scene1 = Union([smooth group (expensive, bounded), room]): the room is evaluated first,
+    # the group behind a test; slots: group = 0 (child 0), room = 1 (child 1)
+    r = rows(compile_scene(R.make_closed_test_scene()))
+    folds = [(int(x[2]), int(x[3])) for x in r if x[0] == _abi.OP_FOLD_MIN]
+    culls = [i for i, x in enumerate(r) if x[0] == _abi.OP_CULL_MIN]
+    assert folds[0] == (1, 0) and folds[1][0] == 0 and folds[1][1] > 0 and len(culls) == 1
+    skip, slot = int(r[culls[0], 3]) >> 8, int(r[culls[0], 3]) & 255
+    assert slot == 0 and r[culls[0] + skip, 0] == _abi.OP_FOLD_MIN and int(r[culls[0] + skip, 3]) == skip
+    # a smooth union alone, cheap leaves, and unbounded children get no test
+    assert _abi.OP_CULL_MIN not in ops(compile_scene(R.make_test_scene()))
+    assert _abi.OP_CULL_MIN not in ops(compile_scene(SDFUnion([SDFSphere(0.3), SDFSphere(0.4)])))
+    assert _abi.OP_CULL_MIN not in ops(compile_scene(SDFUnion([R.make_room(), SDFPlane()])))
+    # knobs: RM_CULL=0 removes them, RM_CULL_MIN_COST=0 tests every boundable child but never the first one
+    # evaluated and never an unbounded one, RM_CULL_REORDER=0 keeps the child order
+    monkeypatch.setenv("RM_CULL", "0")
+    assert _abi.OP_CULL_MIN not in ops(compile_scene(R.make_test_scene2()))
+    monkeypatch.setenv("RM_CULL", "1")
+    monkeypatch.setenv("RM_CULL_MIN_COST", "0")
+    cs = compile_scene(SDFUnion([SDFSphere(0.3), SDFPlane(), SDFSphere(0.4), SDFSphere(0.5)]))
+    r = rows(cs)
+    assert [int(x[2]) for x in r if x[0] == _abi.OP_FOLD_MIN] == [1, 0, 2, 3]       # plane first, then child order
+    assert sum(x[0] == _abi.OP_CULL_MIN for x in r) == 3 and cs.n_derived == 15
+    monkeypatch.setenv("RM_CULL_REORDER", "0")
+    r = rows(compile_scene(SDFUnion([SDFSphere(0.3), SDFPlane(), SDFSphere(0.4)])))
+    assert [int(x[2]) for x in r if x[0] == _abi.OP_FOLD_MIN] == [0, 1, 2]
+    assert sum(x[0] == _abi.OP_CULL_MIN for x in r) == 1                            # only the last sphere
+
+
 def test_foreign_module_is_rejected_loudly():
     from ray_marching_amd.compiler import compile_scene
     from ray_marching_amd.scene.transformations import SDFUnion
