@@ -75,14 +75,69 @@ def run(size=512, march_steps=64, iters=200, lr=1e-3, device="cuda", log=print):
             "bwd_ms": sorted(bwd_ms)[len(bwd_ms) // 2], "losses": losses}
 
 
+def run_graphed(size=512, march_steps=64, iters=200, lr=1e-3, device="cuda", log=print):
+    """The same optimisation with forward + backward + Adam step recorded ONCE in a HIP graph
+    (torch.cuda.graph) and replayed: no Python, no launch gaps between the ~40 small kernels of a step.
+    The replayed trajectory equals the eager one with Adam(capturable=True) digit for digit (checked on the
+    GPU); against run() it drifts, because the two Adam implementations round differently and this
+    problem is ill-conditioned (see the note at the top)."""
+    loop, target_loop = make_problem(size, device)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=device)
+    t = torch.tensor([[0.0, 0.0, -1.0]], device=device)
+    with torch.no_grad():
+        target = target_loop(q, t, 0, 1, march_steps)[..., :1]
+    params = pose_parameters(loop.scene)
+    for p in loop.scene.parameters():
+        p.requires_grad_(any(p is x for x in params))
+    opt = torch.optim.Adam(params, lr=lr, capturable=True)
+
+    def step():
+        loss = (loop(q, t, 0, 1, march_steps)[..., :1] - target).pow(2).mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    warm = 3
+    losses = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):                      # warm-up iterations are real optimiser steps
+            opt.zero_grad(set_to_none=True)
+            losses.append(step().item())
+    torch.cuda.current_stream().wait_stream(side)
+    opt.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    losses.append(float("nan"))                    # the capture pass itself does not execute
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(warm + 1, iters):
+        graph.replay()
+        if it % max(1, iters // 10) == 0 or it == iters - 1:
+            losses.append(loss.item())             # reading the loss synchronises: only every few iterations
+            log(f"iter {it:4d}  loss {losses[-1]:.3e}")
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / max(1, iters - warm - 1) * 1e3
+    finite = [x for x in losses if x == x]
+    return {"loss_first": finite[0], "loss_last": finite[-1], "step_ms": ms, "losses": finite}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--graph", action="store_true", help="record forward + backward + Adam in one HIP graph and replay it")
     a = ap.parse_args()
     t0 = time.time()
+    if a.graph:
+        r = run_graphed(a.size, a.steps, a.iters, a.lr)
+        print(f"loss {r['loss_first']:.3e} -> best {min(r['losses']):.3e} / last {r['loss_last']:.3e} in {a.iters} iterations "
+              f"({time.time() - t0:.1f} s wall); {r['step_ms']:.3f} ms per optimiser step (graph replay) at {a.size}x{a.size}x{a.steps}")
+        sys.exit(0)
     r = run(a.size, a.steps, a.iters, a.lr)
     print(f"loss {r['loss_first']:.3e} -> best {min(r['losses']):.3e} / last {r['loss_last']:.3e} in {a.iters} iterations "
           f"({time.time() - t0:.1f} s wall); median fwd {r['fwd_ms']:.3f} ms, bwd {r['bwd_ms']:.3f} ms at {a.size}x{a.size}x{a.steps}")
