@@ -261,6 +261,19 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build_library()
+        if os.environ.get("RM_SPECIALIZE", "auto") != "off":
+            # the per-scene libraries of the two benchmark scenes (no-op when __graft_entry__.build() made
+            # them; ~10 s of hipcc each on a fresh checkout, where the "auto" policy would otherwise time
+            # the interpreter while the library builds in the background)
+            from ray_marching_amd import specialize
+            from ray_marching_amd.compiler import compile_scene
+            from ray_marching_amd.scene.scene_registry import make_closed_test_scene, make_test_scene2 as _s2
+            try:
+                specialize.build(compile_scene(_s2()), precision=args.precision)
+                if not args.skip_backward:
+                    specialize.build(compile_scene(make_closed_test_scene()))
+            except Exception as e:      # noqa: BLE001  (no hipcc: the interpreter still renders the frame)
+                log(f"specialised libraries not built: {e}")
     if dist is not None:
         dist.barrier()
 
