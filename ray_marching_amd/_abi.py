@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: it carries its own libamdhip64.so (soname libamdhip64.so.7, loaded by path).  If librm_hip.so
+# is opened before it, the loader resolves our libamdhip64.so.7 to /opt/rocm/lib's copy, torch then maps its
+# bundled one next to it, and the process holds two HIP runtimes -- ours then fails every launch with "no
+# ROCm-capable device is detected" (seen on the GPU box with build() followed by smoke() in one process).
+import torch  # noqa: F401,E402
+
 ABI_VERSION = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")

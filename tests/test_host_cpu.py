@@ -159,6 +159,23 @@ def test_compiler_cull_placement_and_evaluation_order(monkeypatch):
     assert sum(x[0] == _abi.OP_CULL_MIN for x in r) == 1                            # only the last sphere
 
 
+def test_one_hip_runtime_whatever_the_import_order():
+    """torch bundles its own libamdhip64.so; if librm_hip.so were opened first the process would map
+    /opt/rocm's copy as well and our launches would fail with "no ROCm-capable device" (seen on the GPU box:
+    build() then smoke() in one process).  _abi imports torch first: one runtime, in either order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for first in ("import ray_marching_amd, torch", "import torch, ray_marching_amd",
+                  "import __graft_entry__ as g; g.build_library(); import ray_marching_amd, torch"):
+        code = (f"import sys; sys.path.insert(0, {root!r}); {first}\n"
+                "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+                "print(len(paths), sorted(paths))")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[0] == "1", (first, r.stdout)
+
+
 def test_foreign_module_is_rejected_loudly():
     from ray_marching_amd.compiler import compile_scene
     from ray_marching_amd.scene.transformations import SDFUnion
