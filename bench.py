@@ -357,11 +357,14 @@ def main():
         evals = rays_per_frame * (STEPS_MARCH + 6)
         ach_gbs = rays_per_frame * BYTES_PER_RAY / (per_launch_ms * 1e-3) / 1e9
         ach_tf = evals * FLOPS_PER_EVAL / (per_launch_ms * 1e-3) / 1e12
-        traffic = None
+        traffic = valu_insts = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(prof):
             with open(prof) as f:
-                traffic = json.load(f).get("k_render_fwd_hbm_bytes_per_launch")
+                pmc = json.load(f)
+            traffic = pmc.get("k_render_fwd_hbm_bytes_per_launch")
+            if specialised and args.precision == "exact" and not args.no_early_out and not args.linear_waves:
+                valu_insts = pmc.get("k_render_fwd_valu_wave_instructions_per_launch")
         out = {
             "metric": "Mrays/sec at 1920x1080x128 iters; fwd+bwd ms/frame",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,7 +387,16 @@ def main():
                          "valu": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach_tf / VALU_PEAK_TFLOPS,
                                   "algorithmic_flops_per_launch": evals * FLOPS_PER_EVAL,
-                                  "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer"}},
+                                  "note": "algorithmic = R*(S+6)*80 flop; the bit-exact early-out executes fewer",
+                                  # executed instructions (SQ_INSTS_VALU, PMC pass in profiles/) against this
+                                  # launch time: SIMD cycles per VALU wave-instruction.  2 = the fp32 rate of
+                                  # two-VGPR-operand arithmetic; ~4 is what this mix of compares, selects,
+                                  # min/max, 3-operand FMAs and scalar operands can issue (DESIGN.md section 8,
+                                  # profiles/micro/valu_issue_bench.hip)
+                                  "executed_wave_instructions": valu_insts,
+                                  "simd_cycles_per_instruction": (None if not valu_insts else
+                                                                  per_launch_ms * 1e-3 * 2.4e9 * 1024 / valu_insts),
+                                  "modelled_issue_cycles_per_instruction": 4.0}},
         }
         if world == 1 and not args.no_pipelined:
             out["other_camera"] = other_camera_probe(loop, q, rows, dev, rays_per_frame, args.camera_z)

@@ -70,5 +70,7 @@ if "SQ_INSTS_VALU" in k and "GRBM_GUI_ACTIVE" in k:
     k["valu_issue_utilisation"] = 2 * k["SQ_INSTS_VALU"] / 1024 / cycles   # wave64 on SIMD32 = 2 cycles/instr
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 json.dump({"source": f"profiles/{tag}_pmc_summary.json",
-           "k_render_fwd_hbm_bytes_per_launch": r_fetch + r_write}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+           "k_render_fwd_hbm_bytes_per_launch": r_fetch + r_write,
+           "k_render_fwd_valu_wave_instructions_per_launch": k.get("SQ_INSTS_VALU")},
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
