@@ -295,13 +295,17 @@ def main():
     comm = torch.cuda.Stream(device=dev) if gather else None
     gathered = None
     if gather and rank == 0:
-        gathered = [[torch.empty(1, H_TILE, W, 3, device=dev) for _ in range(world)] for _ in range(2)]
+        # the Lambertian frame is one value in three channels: it crosses xGMI as one channel (distributed.py)
+        from ray_marching_amd.distributed import GREY_MODES
+        gathered = [[torch.empty(1, H_TILE, W, 1 if m in GREY_MODES else 3, device=dev) for _ in range(world)]
+                    for m in MODES]
 
     kernel_ms = []
 
     def one_step(step_idx, timed):
         handles = []
         from ray_marching_amd import ops
+        from ray_marching_amd.distributed import tile_payload
         for j, mode in enumerate(MODES):
             # HIP events on the launch stream immediately around the k_render_fwd launch (ops.Render.run)
             ops.kernel_event_sink = kernel_ms if timed else None
@@ -313,10 +317,11 @@ def main():
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
                     img.record_stream(comm)
+                    pay = tile_payload(img, mode)
                     if args.backend == "nccl":
-                        dist.gather(img, gathered[j] if rank == 0 else None, dst=0)
+                        dist.gather(pay, gathered[j] if rank == 0 else None, dst=0)
                     else:   # rehearsal backends move host tensors
-                        host = img.cpu()
+                        host = pay.cpu()
                         parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                         dist.gather(host, parts, dst=0)
             handles.append(img)

@@ -23,6 +23,22 @@ import torch
 import torch.distributed as dist
 
 
+# Shaders whose three channels are one value (the reference computes [N,H,W,1] and `.expand`s it,
+# rendering/shader.py:20, 38, 55, 66, 89): lambertian, distance, proximity, vignette, laplacian.  Their tiles
+# cross xGMI as one channel -- a third of the bytes, losslessly -- and are expanded on the receiving side.
+GREY_MODES = (0, 1, 2, 3, 5)
+
+
+def tile_payload(tile: torch.Tensor, mode: int) -> torch.Tensor:
+    """What a rank sends for its tile [N, rows, W, 3]: channel 0 alone for the grey shaders."""
+    return tile[..., :1].contiguous() if mode % 8 in GREY_MODES else tile.contiguous()
+
+
+def expand_payload(frame: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,1] -> the [N,H,W,3] view the reference's Shader.forward returns; 3-channel frames pass."""
+    return frame.expand(-1, -1, -1, 3) if frame.shape[-1] == 1 else frame
+
+
 def row_band(height: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous band [r0, r1) of ``rank``: ceil(height / world) rows each, the last ones shorter
     (possibly empty) so that every gathered tile can be padded to one common size."""
@@ -83,6 +99,7 @@ class RowTileRenderer:
                 lohi = torch.tensor([float("inf"), float("-inf")], device=like.device)
                 self._allreduce_minmax(lohi)
             tile = like.new_zeros((like.shape[0], 0, like.shape[2], 3))
+        tile = tile_payload(tile, mode)
         n, rows, w, c = tile.shape
         padded = tile if rows == per else torch.cat([tile, tile.new_zeros((n, per - rows, w, c))], dim=1)
         padded = padded.contiguous()
@@ -95,7 +112,7 @@ class RowTileRenderer:
             if self.rank != dst:
                 return None
         frame = torch.cat(parts, dim=1)[:, : self.height]
-        return frame
+        return expand_payload(frame)
 
 
 def all_reduce_gradients(module: torch.nn.Module, group=None):

@@ -130,3 +130,20 @@ def test_row_band_covers_every_row_once():
                 assert 0 <= a <= b <= h
                 rows += list(range(a, b))
             assert rows == list(range(h))
+
+
+def test_grey_shader_tiles_travel_as_one_channel():
+    """Lambertian / distance / proximity / vignette / laplacian tiles are one value in three channels
+    (the reference expands a [N,H,W,1] tensor): the gather sends channel 0 and the receiver expands."""
+    from ray_marching_amd.distributed import GREY_MODES, expand_payload, tile_payload
+    grey = torch.rand(1, 5, 7, 1).expand(-1, -1, -1, 3).contiguous()
+    rgb = torch.rand(1, 5, 7, 3)
+    for mode in range(16):
+        if mode % 8 in GREY_MODES:
+            pay = tile_payload(grey, mode)
+            assert pay.shape == (1, 5, 7, 1) and pay.is_contiguous()
+            assert torch.equal(expand_payload(pay), grey)
+        else:
+            pay = tile_payload(rgb, mode)
+            assert pay.shape == rgb.shape and torch.equal(expand_payload(pay), rgb)
+    assert GREY_MODES == (0, 1, 2, 3, 5)
