@@ -144,6 +144,10 @@ struct RegParams {
 // --------------------------------------------------------------------------
 // forward machine
 // --------------------------------------------------------------------------
+#ifndef RM_CULL_TRACKED
+#define RM_CULL_TRACKED 2   // cull sites per scene whose decision is carried from step to step (2 VGPRs each)
+#endif
+
 template <class Store>
 struct Fwd {
   V3 p;        // query point in the current (innermost affine) frame
@@ -157,9 +161,9 @@ struct Fwd {
   // Tracked cull sites (StaticProgram, outermost frame, first kCullTracked of them): per-lane bounds
   // lo <= lhs <= hi on the site's test value lhs = slope |p - c| - K at THIS point, carried over from its
   // last full test through the known movement of the point (Scene::eval_near).  NaN = unknown.
-  float cull_lo[2], cull_hi[2];
+  float cull_lo[RM_CULL_TRACKED], cull_hi[RM_CULL_TRACKED];
 };
-constexpr int kCullTracked = 2;
+constexpr int kCullTracked = RM_CULL_TRACKED;
 
 // Exact culling of a min-union child (RM_OP_CULL_MIN).  The derived block holds a bounding sphere
 // (centre c, radius R; R = +inf when the subtree has none) of the child's surface in the union's frame and
@@ -462,6 +466,7 @@ struct Ins {
 
 // Interpreter; instruction words are wave-uniform (scalar loads when `code` points at global memory).
 struct RuntimeProgram {
+  static constexpr int kTracked = 0;     // the interpreter always runs the full cull test
   const int4* code;
   int n;
   template <class S, class PT>
@@ -509,6 +514,13 @@ struct StaticProgram {
     }
     return (depth == 0 && k < kCullTracked) ? k : -1;
   }
+  static constexpr int count_tracked() {
+    int k = 0;
+    for (int i = 0; i < Code::n; ++i)
+      if (Code::code[i].op == RM_OP_CULL_MIN && tracked_site(i) >= 0) ++k;
+    return k;
+  }
+  static constexpr int kTracked = count_tracked();
   // executes instructions [PC, END)
   template <int PC, int END, class S, class PT>
   RM_DEV void fwd_range(S& s, const PT& P) const {
@@ -566,8 +578,7 @@ struct Scene {
   int acc0;    // store index of gradient accumulator 0 (= stack_floats + n_slots)
 
   // bounds of the tracked cull sites at the point of the previous evaluation (per lane; NaN = unknown)
-  mutable float cull_lo[kCullTracked] = {__builtin_nanf(""), __builtin_nanf("")};
-  mutable float cull_hi[kCullTracked] = {__builtin_nanf(""), __builtin_nanf("")};
+  mutable float cull_lo[kCullTracked] = {}, cull_hi[kCullTracked] = {};   // meaningful after the first evaluation (move = NaN)
 
   // f(p) where p is at most `move` away from the point of this context's previous evaluation (NaN: no
   // such knowledge).  Identical value; the knowledge only decides which cull tests can be skipped.
@@ -576,10 +587,14 @@ struct Scene {
     s.p = p; s.d = 0.0f; s.acc = __builtin_inff(); s.sp = 0; s.tape0 = tape0; s.st = st; s.record = record;
     s.culled = 0ull;
 #pragma unroll
-    for (int k = 0; k < kCullTracked; ++k) { s.cull_lo[k] = cull_lo[k] - move; s.cull_hi[k] = cull_hi[k] + move; }
+    for (int k = 0; k < Prog::kTracked; ++k) {
+      // (move != move: nothing is known, e.g. on the first evaluation of a tile)
+      s.cull_lo[k] = (move == move) ? cull_lo[k] - move : move;
+      s.cull_hi[k] = (move == move) ? cull_hi[k] + move : move;
+    }
     prog.forward(s, P);
 #pragma unroll
-    for (int k = 0; k < kCullTracked; ++k) { cull_lo[k] = s.cull_lo[k]; cull_hi[k] = s.cull_hi[k]; }
+    for (int k = 0; k < Prog::kTracked; ++k) { cull_lo[k] = s.cull_lo[k]; cull_hi[k] = s.cull_hi[k]; }
     return s.d;
   }
   RM_DEV float eval(V3 p, bool record = false) const { return eval_near(p, __builtin_nanf(""), record); }
@@ -590,7 +605,7 @@ struct Scene {
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
     f.culled = 0ull;
 #pragma unroll
-    for (int k = 0; k < kCullTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
+    for (int k = 0; k < Prog::kTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
     prog.forward(f, P);
     if (value) *value = f.d;
     Bwd<Store> b;
