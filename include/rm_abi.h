@@ -173,6 +173,12 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
                       int32_t mode, int32_t degree, int32_t steps,
                       int32_t row_begin, int32_t row_end, int32_t flags, void* stream);
 
+/* Experiment hook (profiles/tile_order_probe.py), not part of the drop-in surface: a device int32 permutation
+ * "position in the dealing order -> wave tile" used by every later rm_render_forward of THIS library
+ * (process-global, not stream-safe); NULL restores the natural order.  Longest-first orders built from the
+ * previous frame's step counts bought nothing at the benchmark camera and 10 % at (0,0,1) -- DESIGN.md 6. */
+int rm_debug_tile_order(const int32_t* order /*device, nullable*/);
+
 /* workspace helpers: init (min=+inf, max=-inf, no NaN, all tile counters 0; the buffer holds
  * RM_WORK_WORDS uint32); decode to two floats {lo, hi};
  * encode two floats back (after a host-side all-reduce). */

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "rm_render_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
                                     _P, _P, _P, _P, _P, _P, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "rm_debug_tile_order": (C.c_int, [_P]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),

@@ -44,6 +44,8 @@ int check_scene(const RmScene* sc) {
   return check_static(sc);
 }
 
+static const int32_t* g_debug_tile_order = nullptr;   // experiment hook (rm_debug_tile_order)
+
 struct Launch {
   int block;
   size_t lds;
@@ -272,6 +274,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   a.image = image; a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.minmax = minmax;
   a.cmap = cmap; a.cmap_size = cmap_size;
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
+  a.tile_order = g_debug_tile_order;
   Launch L;
   if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
   int64_t wave_tiles;
@@ -285,6 +288,8 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   return launched("k_render_fwd");
 }
+
+int rm_debug_tile_order(const int32_t* order) { g_debug_tile_order = order; return RM_OK; }
 
 int rm_minmax_init(uint32_t* minmax, void* stream) {
   if (!minmax) return fail(RM_E_BADARG, "rm_minmax_init: null");

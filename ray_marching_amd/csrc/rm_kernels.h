@@ -437,6 +437,7 @@ struct RenderArgs {
   const float* cmap;         // nullable
   int32_t cmap_size;
   int32_t mode, degree, steps, row_begin, row_end, flags;
+  const int32_t* tile_order; // nullable: position in the dealing order -> wave tile (longest-first schedules)
   // backward only
   const float* grad_image;
   float* partials;
@@ -754,7 +755,8 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   const int64_t ntiles = wave_tiles(a);
 
   for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
-    TileRays r = load_tile_rays(a, tc.tile);
+    const int64_t tile = a.tile_order ? (int64_t)a.tile_order[tc.tile] : tc.tile;
+    TileRays r = load_tile_rays(a, tile);
     int nexec;
     V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec);
     finish_tile(a, scene, T, r, p, nexec, mm);
