@@ -760,6 +760,57 @@ def test_tracked_culls_in_specialised_kernels_change_no_bit(case, monkeypatch):
         assert torch.equal(a.isnan(), b.isnan())
 
 
+@pytest.mark.parametrize("case,seed", [("scene1c", 0), ("scene1c", 1), ("many32", 2), ("scene2", 3)])
+def test_cull_bounds_follow_the_live_parameters(case, seed, monkeypatch):
+    """The cull bounds are derived on the device from the parameters of THIS launch.  Scenes whose objects
+    were moved against the walls, resized and given far-from-unit quaternions (the state a scene is in
+    half-way through an optimisation) still render bit-identically with the specialised, culling,
+    decision-carrying kernels and with the interpreter compiled without CULL_MIN."""
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import (make_closed_test_scene, make_many_primitive_scene,
+                                                       make_test_scene2)
+    make = {"scene2": make_test_scene2, "scene1c": make_closed_test_scene,
+            "many32": lambda: make_many_primitive_scene(32)}[case]
+    gen = torch.Generator().manual_seed(4242 + seed)
+    state = {}
+    for name, p in make().named_parameters():
+        x = p.detach().clone()
+        if name.endswith("translation") or name.endswith("start") or name.endswith("end"):
+            x = x + (torch.rand(x.shape, generator=gen) * 6 - 3)
+        elif name.endswith("orientation"):
+            x = (x + torch.randn(x.shape, generator=gen) * 0.3) * (0.8 + 0.5 * torch.rand(1, generator=gen))
+        elif name.endswith("blend_k"):
+            x = (x * (0.3 + 1.5 * torch.rand(1, generator=gen))).reshape(x.shape)
+        elif "sdfs.0." in name and case != "scene1c" or name == "sdfs.1.sdf.halfsides" or name == "sdfs.1.radius":
+            pass                                         # keep the room where it is
+        else:
+            x = x * (0.4 + 1.6 * torch.rand(x.shape, generator=gen))
+        state[name] = x
+    poses = [([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, -3.0]), ([0.9239, 0.0, 0.3827, 0.0], [4.0, -3.5, -4.0])]
+    frames = {}
+    for variant in ("interp_nocull", "static_tracked"):
+        monkeypatch.setenv("RM_CULL", "0" if variant == "interp_nocull" else "1")
+        monkeypatch.setenv("RM_SPECIALIZE", "off" if variant == "interp_nocull" else "auto")
+        specialize._loaded.clear()
+        scene = make()
+        with torch.no_grad():
+            for name, p in scene.named_parameters():
+                p.copy_(state[name])
+        loop = H.make_loop(scene, 64, 96)
+        assert compiled_for(loop.scene).specialised == (variant == "static_tracked")
+        out = []
+        with torch.no_grad():
+            for q, t in poses:
+                qq = torch.tensor([q], device=DEV); tt = torch.tensor([t], device=DEV)
+                out += [loop(qq, tt, m, 1, 96) for m in (4, 0)]
+        frames[variant] = out
+    specialize._loaded.clear()
+    for a, b in zip(frames["interp_nocull"], frames["static_tracked"]):
+        assert torch.equal(a.isnan(), b.isnan())
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+
+
 def test_training_step_captured_in_a_graph_matches_eager():
     """forward + backward of the fused frame (config 4 shape, small) recorded with torch.cuda.graph:
     the replayed gradients equal the eager ones (up to the grouping of per-block partial sums, which
