@@ -608,9 +608,9 @@ struct Scene {
     s.culled = 0ull;
 #pragma unroll
     for (int k = 0; k < Prog::kTracked; ++k) {
-      // (move != move: nothing is known, e.g. on the first evaluation of a tile)
-      s.cull_lo[k] = (move == move) ? cull_lo[k] - move : move;
-      s.cull_hi[k] = (move == move) ? cull_hi[k] + move : move;
+      // move = NaN (nothing known: first evaluation of a tile, every 16th step) turns both bounds into NaN
+      s.cull_lo[k] = cull_lo[k] - move;
+      s.cull_hi[k] = cull_hi[k] + move;
     }
     prog.forward(s, P);
 #pragma unroll
