@@ -4,7 +4,7 @@ compiled with a cull test in front of EVERY boundable union child (RM_CULL_MIN_C
 (RM_CULL=0); values at 16 k points and point gradients must be bit-identical.  Parameter gradients are sums
 over the points, reduced per block: the longer program changes the interpreter's LDS footprint and with it the
 block size rm_abi.hip picks, so their partial sums may be grouped differently -- they are compared to 1e-3 of
-the largest component instead (found by this fuzz: 11 of 134 trees, values and point gradients identical).
+the largest component plus 2e-6 of the scene's largest gradient instead (found by this fuzz: 11 of 134 trees, values and point gradients identical).
     python tests/fuzz_cull.py [n_seeds]        (a script, not collected by pytest: ~1 s per tree)"""
 import os, sys
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,9 +49,12 @@ for seed in seeds:
         (d * wts).sum().backward()
         res[cull] = (d.detach(), p.grad, [None if x.grad is None else x.grad.clone() for x in module.parameters()], n_cull)
     a, b = res["0"], res["1"]
+    gmax = max([float(torch.nan_to_num(x).abs().max()) for x in a[2] if x is not None] + [0.0])
     def close(x, y):
+        # cancellation: a component of 1e-4 can be the sum of terms of order gmax, so part of the allowance
+        # scales with the largest gradient of the scene
         fx, fy = torch.nan_to_num(x.double()), torch.nan_to_num(y.double())
-        return torch.equal(x.isnan(), y.isnan()) and float((fx - fy).abs().max()) <= 1e-3 * float(fx.abs().max()) + 1e-12
+        return torch.equal(x.isnan(), y.isnan()) and float((fx - fy).abs().max()) <= 1e-3 * float(fx.abs().max()) + 2e-6 * gmax + 1e-12
     ok = same(a[0], b[0]) and same(a[1], b[1]) and all((x is None) == (y is None) and (x is None or close(x, y)) for x, y in zip(a[2], b[2]))
     with_culls += b[3] > 0; total_culls += b[3]
     if not ok:
