@@ -15,8 +15,11 @@
  *     void*; NULL = the default stream); calls are re-entrant per stream;
  *   - return value 0 = enqueued, negative = error (RM_E_*), message available
  *     from rm_last_error() on the calling thread; no C++ exception crosses;
- *   - all arithmetic is IEEE fp32 (RM_DTYPE_F32).  Arrays are contiguous,
- *     channels-last: points [n,3], images [N,rows,W,3].
+ *   - all arithmetic is IEEE fp32.  Arrays are contiguous, channels-last: points [n,3], images
+ *     [N,rows,W,3].  The forward entry points take the element type of their I/O arrays as an
+ *     RM_DTYPE_* argument (the reference module cast with .to(dtype), main.py:20-26 runs float16):
+ *     fp16 arrays are converted in the kernels' loads and stores, there is no separate cast pass.
+ *     Backward entry points are fp32 only.
  */
 #ifndef RM_ABI_H
 #define RM_ABI_H
@@ -27,7 +30,14 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 8
+#define RM_ABI_VERSION 9
+
+enum {
+  RM_DTYPE_F32 = 0,
+  RM_DTYPE_F16 = 1,      /* IEEE binary16 storage, fp32 arithmetic */
+  RM_DTYPE_F64 = 2       /* images / colormap of the tangent and spin shaders only: the reference multiplies an
+                            fp32 brightness by its float64 colormap, giving a float64 image (shader.py:104,118) */
+};
 
 enum {
   RM_OK = 0,
@@ -68,9 +78,20 @@ enum {
   RM_OP__COUNT = 18
 };
 
+/* Where one float of the parameter block lives: element `elem` of a device array of `dtype` (F32 or F16).
+ * A table of n_params of these lets the kernels gather the block straight from the nn.Parameter storages in
+ * their prologue, so an inference frame needs no packing pass and can never see stale values (in-place edits,
+ * optimiser steps and .data writes are all just memory the next launch reads). */
+typedef struct RmParamRef {
+  const void* base;
+  int32_t elem;
+  int32_t dtype;
+} RmParamRef;
+
 typedef struct RmScene {
   const int32_t* program;  /* device, n_instr * 4 int32 */
-  const float* params;     /* device, n_params fp32 (raw parameters) */
+  const float* params;     /* device, n_params fp32 (raw parameters, packed); may be NULL when param_refs is given */
+  const RmParamRef* param_refs; /* device, n_params entries, or NULL: gather the block from here instead of `params` */
   int32_t n_instr;
   int32_t n_params;        /* raw parameter floats = length of every grad_params vector */
   int32_t n_derived;       /* derived constants appended in LDS after the raw block */
@@ -80,9 +101,11 @@ typedef struct RmScene {
 
 /* PinholeCamera buffers (rendering/ray_marching.py:26-50). */
 typedef struct RmCamera {
-  const float* ray_positions;   /* device [N,H,W,3] camera-frame origins */
-  const float* ray_directions;  /* device [N,H,W,3] camera-frame unit directions */
+  const void* ray_positions;    /* device [N,H,W,3] camera-frame origins */
+  const void* ray_directions;   /* device [N,H,W,3] camera-frame unit directions */
   int32_t num_cameras, height, width;
+  int32_t dtype;                /* RM_DTYPE_F32 or RM_DTYPE_F16: element type of the two buffers and of the
+                                   orientation / translation arrays passed along with them */
 } RmCamera;
 
 /* SDFNormals constants (rendering/ray_marching.py:96-113), host memory. */
@@ -123,8 +146,8 @@ const char* rm_last_error(void);
 int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n);
 
 /* scene(query[...,3]) -> [...,1]          (every forward() in scene/primitives.py, transformations.py) */
-int rm_sdf_forward(const RmScene* scene, const float* points /*device [n,3]*/,
-                   float* dist /*device [n]*/, int64_t n, void* stream);
+int rm_sdf_forward(const RmScene* scene, const void* points /*device [n,3]*/,
+                   void* dist /*device [n]*/, int64_t n, int32_t dtype /*F32 | F16, both arrays*/, void* stream);
 
 /* VJP of rm_sdf_forward: grad_points[n,3] (nullable) and grad_params[n_params]
  * (nullable, OVERWRITTEN with the deterministic sum over rays). */
@@ -134,8 +157,9 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
 /* SDFMarcher.forward (rendering/ray_marching.py:72-84): p <- f(p)*v + p, `steps` times.
  * traj (nullable): device [steps,n,3], iterate p_i BEFORE step i (needed by backward).
  * nexec (nullable): device int32 [n], steps executed before the early-out fixed point. */
-int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, float* out_pos,
-                     float* traj, int32_t* nexec, int64_t n, int32_t steps, int32_t flags, void* stream);
+int rm_march_forward(const RmScene* scene, const void* pos, const void* dirs, void* out_pos,
+                     float* traj, int32_t* nexec, int64_t n, int32_t steps, int32_t flags,
+                     int32_t dtype /*F32 | F16: pos, dirs, out_pos; traj is always fp32*/, void* stream);
 
 /* VJP of rm_march_forward w.r.t. pos, dirs (nullable) and parameters. */
 int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj, const int32_t* nexec,
@@ -143,41 +167,48 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
                       float* grad_params, float* partials, int64_t n, int32_t steps, void* stream);
 
 /* SDFNormals.forward (rendering/ray_marching.py:115-125). */
-int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* coords /*[n,3]*/,
-                       float* normals /*[n,3]*/, float* laplacian /*[n]*/, int64_t n, void* stream);
+int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const void* coords /*[n,3]*/,
+                       void* normals /*[n,3]*/, void* laplacian /*[n]*/, int64_t n,
+                       int32_t dtype /*F32 | F16, all three arrays*/, void* stream);
 
 int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float* coords,
                         const float* grad_normals /*[n,3] nullable*/, const float* grad_lap /*[n] nullable*/,
                         float* grad_coords, float* grad_params, float* partials, int64_t n, void* stream);
 
-/* PinholeCamera.forward (rendering/ray_marching.py:57-64). frames: [N,3,3]. */
-int rm_camera_forward(const RmCamera* cam, const float* orientation /*device [N,4]*/,
-                      const float* translation /*device [N,3]*/, float* out_pos, float* out_dirs,
-                      float* out_frames, void* stream);
+/* PinholeCamera.forward (rendering/ray_marching.py:57-64). frames: [N,3,3].  Every array has cam->dtype. */
+int rm_camera_forward(const RmCamera* cam, const void* orientation /*device [N,4]*/,
+                      const void* translation /*device [N,3]*/, void* out_pos, void* out_dirs,
+                      void* out_frames, void* stream);
 
 /* RenderLoop.forward (control.py:231-258), fused: camera -> march -> distance ->
  * normals/laplacian -> shader, rows [row_begin,row_end) of every camera.
- *   image   : device [N,rows,W,3] fp32.
- *   p_final : nullable [N,rows,W,3]; traj: nullable [steps,N*rows*W,3]; nexec nullable.
+ *   orientation, translation : device [N,4], [N,3], element type cam->dtype.
+ *   image   : device [N,rows,W,3] of image_dtype (F32, F16; F64 for modes 6,7 with a float64 colormap).
+ *   p_final : nullable fp32 [N,rows,W,3]; traj: nullable fp32 [steps,N*rows*W,3]; nexec nullable.
  *   minmax  : device uint32[RM_WORK_WORDS] prepared by rm_minmax_init.  Holds the tile queues of
  *             RM_FLAG_DYNAMIC_TILES (NULL = static striding).  Words 0-2 are required for modes 1,2,5
- *             (global min/max, shader.py:35-36, 52-53, 84).  The kernel leaves the un-normalised value in `image` and folds
- *             its min/max into minmax; rm_shade_finish() then normalises.  Between the two
- *             calls a multi-GPU host all-reduces minmax (rm_minmax_* helpers).
- *   cmap    : device fp32 [cmap_size,3], required for modes 6,7.
+ *             (global min/max, shader.py:35-36, 52-53, 84).
+ *   first_pass : modes 1,2,5 only: device fp32 [N,rows,W,3] receiving the un-normalised value (it may alias
+ *             `image` when image_dtype is F32); the kernel folds its min/max into minmax and
+ *             rm_shade_finish(first_pass -> image) normalises.  Between the two calls a multi-GPU host
+ *             all-reduces minmax (rm_minmax_* helpers).
+ *   cmap    : device [cmap_size,3] of cmap_dtype (F32, F16 or F64), required for modes 6,7.
+ *   tile_order : nullable device int32[T] permutation of the T wave tiles (T = rm_wave_tiles()): the tile
+ *             dealt at position i is tile_order[i].  Waves draw positions in increasing order, so an order
+ *             sorted by decreasing cost (e.g. the previous frame's tile_cost) shortens the tail of the launch;
+ *             any permutation gives the same image.
+ *   tile_cost : nullable device int32[T] out: march steps the wave of each tile executed.
  */
 int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
-                      const float* orientation, const float* translation,
-                      float* image, float* p_final, float* traj, int32_t* nexec,
-                      uint32_t* minmax, const float* cmap, int32_t cmap_size,
+                      const void* orientation, const void* translation,
+                      void* image, int32_t image_dtype, float* first_pass, float* p_final, float* traj, int32_t* nexec,
+                      uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype,
                       int32_t mode, int32_t degree, int32_t steps,
-                      int32_t row_begin, int32_t row_end, int32_t flags, void* stream);
+                      int32_t row_begin, int32_t row_end, int32_t flags,
+                      const int32_t* tile_order, int32_t* tile_cost, void* stream);
 
-/* Experiment hook (profiles/tile_order_probe.py), not part of the drop-in surface: a device int32 permutation
- * "position in the dealing order -> wave tile" used by every later rm_render_forward of THIS library
- * (process-global, not stream-safe); NULL restores the natural order.  Longest-first orders built from the
- * previous frame's step counts bought nothing at the benchmark camera and 10 % at (0,0,1) -- DESIGN.md 6. */
-int rm_debug_tile_order(const int32_t* order /*device, nullable*/);
+/* number of wave tiles (64-ray work units) of a band of `rows` rows: length of tile_order / tile_cost */
+int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t flags);
 
 /* workspace helpers: init (min=+inf, max=-inf, no NaN, all tile counters 0; the buffer holds
  * RM_WORK_WORDS uint32); decode to two floats {lo, hi};
@@ -186,16 +217,20 @@ int rm_minmax_init(uint32_t* minmax /*device*/, void* stream);
 int rm_minmax_decode(const uint32_t* minmax, float* lohi /*device [2]*/, void* stream);
 int rm_minmax_encode(const float* lohi /*device [2]*/, uint32_t* minmax, void* stream);
 
-/* second pass of the globally normalised shaders (modes 1, 2, 5), in place on image[n_pixels,3]. */
-int rm_shade_finish(float* image, int64_t n_pixels, const uint32_t* minmax, int32_t mode, void* stream);
+/* second pass of the globally normalised shaders (modes 1, 2, 5): first_pass fp32 [n_pixels,3] -> image
+ * [n_pixels,3] of image_dtype (F32 or F16); in place when the two pointers are equal (F32 only). */
+int rm_shade_finish(const float* first_pass, void* image, int32_t image_dtype, int64_t n_pixels,
+                    const uint32_t* minmax, int32_t mode, void* stream);
 
 /* Shader.forward on tensors (rendering/shader.py:190-263): first pass for every mode.
- * Inputs a mode does not read may be NULL.  frames: [N,3,3]; per-pixel arrays hold
- * n_pixels = N * pixels_per_camera entries.  Modes 1,2,5 need minmax + rm_shade_finish. */
+ * Inputs (fp32) a mode does not read may be NULL.  frames: [N,3,3]; per-pixel arrays hold
+ * n_pixels = N * pixels_per_camera entries.  image: [n_pixels,3] of image_dtype -- except for modes 1,2,5,
+ * where it receives the fp32 first-pass values (image_dtype must be F32) and minmax + rm_shade_finish follow. */
 int rm_shade_forward(const float* px_coords, const float* orientation, const float* frames, const float* dirs,
-                     const float* coords, const float* normals, const float* lap, const float* dist, float* image,
-                     uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
-                     int64_t n_pixels, int64_t pixels_per_camera, void* stream);
+                     const float* coords, const float* normals, const float* lap, const float* dist,
+                     void* image, int32_t image_dtype,
+                     uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype, int32_t mode,
+                     int32_t degree, int64_t n_pixels, int64_t pixels_per_camera, void* stream);
 
 /* VJP of rm_shade_forward for the per-pixel shaders that have one: Lambertian (0), vignette (3),
  * normal (4).  grad_image: [n_pixels, 1] (modes 0, 3) or [n_pixels, 3] (mode 4).  Outputs nullable. */
@@ -204,7 +239,7 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
                       int64_t pixels_per_camera, void* stream);
 
 /* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
- * grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
+ * fp32 only (cam->dtype must be RM_DTYPE_F32).  grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
  * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT
  * stops a wave's reverse sweep once every ray's adjoint component along the ray is below the

@@ -19,6 +19,7 @@ Fixture families:
   f6_ties.npz       subgradient choices at ties
   f7_*fp16*.npz     reference cast to float16 (config 3 numerics) + its own fp16-vs-fp32 spread
   f8_*two_cameras   num_cameras = 2 batch
+  f9_many32_*.npz   config-5 scene (32-primitive smooth union in a room), 54x96 S=128, modes 0 and 4
   cmap.npz          the reference's colormap data file (float64 [4096,3])
 """
 from __future__ import annotations
@@ -255,7 +256,25 @@ def gen_f8(ref):
          mode1=npy(images[1][..., :1]), mode4=npy(images[4]))
 
 
+def gen_f9(ref):
+    """Config-5 scene at a size the reference renders in seconds.  The smooth union goes through
+    torch.logsumexp = MKL VML exp/log, whose bits depend on the host CPU: this fixture holds the build
+    container's (Intel) result, and the GPU test also reports how far the GPU box's own CPU lands from it."""
+    h, w, steps = 54, 96, 128
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -4.5]])
+    images, aux = frame(ref, O.scene_many(32), h, w, q, t, steps, [0, 4], degree=1)
+    save("f9_many32_54x96_s128.npz", hw=np.array([h, w]), steps=np.array(steps), q=npy(q), t=npy(t),
+         eps=np.array(EPS), p=npy(aux["p"]), n=npy(aux["n"]), dist=npy(aux["dist"]),
+         mode0=npy(images[0][..., :1]), mode4=npy(images[4]))
+
+
 def main():
+    if len(sys.argv) > 1:          # python oracle/gen_golden.py f9  -> only that family
+        torch.set_num_threads(8)
+        ref = ref_bridge.load_reference()
+        for name in sys.argv[1:]:
+            globals()["gen_" + name](ref)
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_bridge.load_reference()
@@ -267,6 +286,7 @@ def main():
     gen_f6(ref)
     gen_f7(ref)
     gen_f8(ref)
+    gen_f9(ref)
     save("cmap.npz", cyclic_cmap=npy(ref.shader.cyclic_cmap))
 
 

@@ -14,7 +14,7 @@ import os
 # ROCm-capable device is detected" (seen on the GPU box with build() followed by smoke() in one process).
 import torch  # noqa: F401,E402
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
 
@@ -27,20 +27,27 @@ OP_ROUND, OP_ONION = 15, 16
 OP_CULL_MIN = 17
 
 FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES = 1, 2, 4
+DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2      # RM_DTYPE_*
+_DTYPES = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.float64: DTYPE_F64}
+
+
+def dtype_code(dtype) -> int:
+    """RM_DTYPE_* of a torch dtype (KeyError for anything the kernels cannot read or write)."""
+    return _DTYPES[dtype]
 WORK_WORDS = 64 + 64 * 32   # RM_WORK_WORDS
 CAMERA_BWD_BLOCKS = 256     # RM_CAMERA_BWD_BLOCKS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 
 
 class RmScene(C.Structure):
-    _fields_ = [("program", C.c_void_p), ("params", C.c_void_p), ("n_instr", C.c_int32),
+    _fields_ = [("program", C.c_void_p), ("params", C.c_void_p), ("param_refs", C.c_void_p), ("n_instr", C.c_int32),
                 ("n_params", C.c_int32), ("n_derived", C.c_int32), ("stack_floats", C.c_int32),
                 ("n_slots", C.c_int32)]
 
 
 class RmCamera(C.Structure):
     _fields_ = [("ray_positions", C.c_void_p), ("ray_directions", C.c_void_p),
-                ("num_cameras", C.c_int32), ("height", C.c_int32), ("width", C.c_int32)]
+                ("num_cameras", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("dtype", C.c_int32)]
 
 
 class RmTetra(C.Structure):
@@ -57,23 +64,23 @@ _SIGNATURES = {
     "rm_last_error": (C.c_char_p, []),
     "rm_grad_partials_floats": (C.c_int64, [C.POINTER(RmScene), C.c_int64]),
     "rm_validate_program": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    "rm_sdf_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, C.c_int64, _P]),
+    "rm_sdf_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, C.c_int64, C.c_int32, _P]),
     "rm_sdf_backward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, C.c_int64, _P]),
-    "rm_march_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "rm_march_forward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P]),
     "rm_march_backward": (C.c_int, [C.POINTER(RmScene), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P]),
-    "rm_normals_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, C.c_int64, _P]),
+    "rm_normals_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, C.c_int64, C.c_int32, _P]),
     "rm_normals_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "rm_camera_forward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P]),
     "rm_render_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
-                                    _P, _P, _P, _P, _P, _P, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "rm_debug_tile_order": (C.c_int, [_P]),
+                                    _P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rm_wave_tiles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),
-    "rm_shade_finish": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P]),
-    "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_int64, C.c_int64, _P]),
+    "rm_shade_finish": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
+    "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_shade_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIBDIR, "librm_hip.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("rm_abi.hip", "rm_kernels.h", "rm_device.h")] + \
+SOURCES = [os.path.join(CSRC, f) for f in ("rm_abi.hip", "rm_kernels.h", "rm_device.h", "rm_math.h")] + \
     [os.path.join(os.path.dirname(_HERE), "include", "rm_abi.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-shared", "-fPIC", "-std=c++17"]
 # opt-in "fast" arithmetic (RenderLoop(precision="fast")): 1-ulp v_sqrt_f32, reciprocal normalise, FMA

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -74,8 +76,15 @@ class CompiledScene:
     n_slots: int
     signature: tuple                    # topology key (ops + offsets), parameters excluded
     _device_programs: dict = field(default_factory=dict)
-    _packed: dict = field(default_factory=dict)
+    _table: dict = field(default_factory=dict)
     _lib: object = None
+
+    # the loaded libraries (ctypes) and device tensors are process state, not scene state: a pickled / deep-copied
+    # CompiledScene carries the program only and re-resolves the rest on first use
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_device_programs"], state["_table"], state["_lib"] = {}, {}, None
+        return state
 
     def lib(self, backward: bool = False, precision: str = "exact"):
         """Kernel library for this scene: the per-scene specialised build when one is available
@@ -111,31 +120,59 @@ class CompiledScene:
         return t
 
     def pack_params(self, device):
-        """fp32 parameter block on ``device``.  Differentiable (torch.cat) when any
-        leaf requires grad and grad mode is on; otherwise cached on the leaves'
-        version counters so inference frames do not re-pack."""
+        """fp32 parameter block on ``device`` as ONE tensor (torch.cat of the leaves: differentiable, so
+        gradients flow back to every nn.Parameter).  Always rebuilt from the live values -- no cache that an
+        in-place ``.data`` edit could leave stale.  Inference frames do not need it at all: see param_table."""
         leaves = self.leaves
         if not leaves:
             return torch.zeros(1, dtype=torch.float32, device=device)
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in leaves)
-        if not needs_grad:
-            key = (str(device),) + tuple((p.data_ptr(), p._version, p.dtype) for p in leaves)
-            hit = self._packed.get("key") == key
-            if hit:
-                return self._packed["value"]
-        flat = torch.cat([p.reshape(-1).to(device=device, dtype=torch.float32) for p in leaves])
-        if not needs_grad:
-            self._packed = {"key": key, "value": flat.detach()}
-            return self._packed["value"]
-        return flat
+        return torch.cat([p.reshape(-1).to(device=device, dtype=torch.float32) for p in leaves])
 
-    def scene_struct(self, params, device):
-        """RmScene for a launch; keeps the referenced tensors alive via the return tuple."""
+    def param_table(self, device):
+        """Device table of RmParamRef {pointer, element, dtype} for every float of the block, so the kernels
+        gather the parameters from the nn.Parameter storages themselves (no packing pass; in-place edits,
+        optimiser steps and ``.data`` writes are simply what the next launch reads).  The table only depends
+        on where the leaves live -- (data_ptr, dtype), all visible on the host -- and is rebuilt when that
+        changes.  None when a leaf cannot be read in place (not on ``device``, not fp32/fp16, not contiguous);
+        the caller then packs."""
+        leaves = self.leaves
+        if not leaves:
+            return None
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        key = (str(dev),) + tuple((p.data_ptr(), p.dtype) for p in leaves)
+        hit = self._table.get("key")
+        if hit == key:
+            return self._table["value"]
+        rows = np.zeros((self.n_params, 2), dtype=np.int64)        # {base pointer, elem | dtype << 32}
+        at = 0
+        for p in leaves:
+            if p.device != dev or p.dtype not in (torch.float32, torch.float16) or not p.is_contiguous():
+                self._table = {"key": key, "value": None}
+                return None
+            n = p.numel()
+            rows[at:at + n, 0] = p.data_ptr()
+            rows[at:at + n, 1] = np.arange(n, dtype=np.int64) | (np.int64(_abi.dtype_code(p.dtype)) << 32)
+            at += n
+        table = torch.from_numpy(rows.reshape(-1)).to(dev)
+        self._table = {"key": key, "value": table}
+        return table
+
+    def scene_struct(self, params, device, table=None):
+        """RmScene for a launch; keeps the referenced tensors alive via the return tuple.  ``params``: the packed
+        fp32 block, or None to gather from ``table`` (default: param_table(device)); packs when neither works."""
         prog = self.device_program(device)
-        s = _abi.RmScene(program=prog.data_ptr(), params=params.data_ptr(), n_instr=self.n_instr,
-                         n_params=self.n_params, n_derived=self.n_derived,
+        if params is None and table is None:
+            table = self.param_table(device)
+            if table is None:
+                with torch.no_grad():
+                    params = self.pack_params(device)
+        s = _abi.RmScene(program=prog.data_ptr(), params=None if params is None else params.data_ptr(),
+                         param_refs=None if (params is not None or table is None) else table.data_ptr(),
+                         n_instr=self.n_instr, n_params=self.n_params, n_derived=self.n_derived,
                          stack_floats=self.stack_floats, n_slots=self.n_slots)
-        return s, (prog, params)
+        return s, (prog, params, table)
 
 
 class _Emitter:
@@ -201,6 +238,9 @@ def _emit(node, em: _Emitter, n_params: int):
         kids = list(node.sdfs)
         if not kids:
             raise ValueError("SDFUnion / SDFSmoothUnion needs at least one child")
+        if kind == "smooth_union" and len(kids) >= 512:
+            raise NotImplementedError("SDFSmoothUnion with 512 or more children: ATen's sum kernel switches to cascade "
+                                      "levels there, which the kernels' summation order (aten_inner_sum) does not follow")
         base = em.n_slots
         em.n_slots += len(kids)
         smooth = kind == "smooth_union"
@@ -286,11 +326,15 @@ def structure_key(module: nn.Module):
     return tuple(out)
 
 
+_compiled = weakref.WeakKeyDictionary()      # module -> (structure key, CompiledScene); NOT in the module's own
+                                              # state: copy.deepcopy / torch.save of a scene or RenderLoop must work
+
+
 def compiled_for(module: nn.Module) -> CompiledScene:
-    """Compile once per (module instance, topology) and cache on the module."""
+    """Compile once per (module instance, topology)."""
     key = structure_key(module)
-    cache = module.__dict__.get("_rm_compiled")
+    cache = _compiled.get(module)
     if cache is None or cache[0] != key:
         cache = (key, compile_scene(module))
-        module.__dict__["_rm_compiled"] = cache
+        _compiled[module] = cache
     return cache[1]

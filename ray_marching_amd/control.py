@@ -22,29 +22,41 @@ from .rendering.shader import Shader
 class CapturedFrame:
     """One inference frame of a RenderLoop captured into a HIP graph (torch.cuda.CUDAGraph).
 
-    A frame is 2-3 kernel launches (workspace init, k_render_fwd, optional k_shade_finish) plus a few
-    hundred microseconds of Python; for small frames (main.py's 1440x900x32 takes ~0.15 ms of GPU time)
-    the host side dominates.  Replaying a captured graph removes it.  Pose and scene parameters live in
-    static device buffers that are refreshed (one tiny copy each) before every replay, so moving the camera
-    or editing / optimising scene parameters needs no re-capture; changing mode, steps, resolution or the
-    scene topology does.  Inference only (no autograd)."""
+    A frame is 2-3 kernel launches (workspace init, k_render_fwd, optional k_shade_finish) plus some tens of
+    microseconds of Python; for small frames (main.py's 1440x900x32 takes ~0.15 ms of GPU time) the host side
+    matters.  Replaying a captured graph removes it.  The pose lives in static device buffers refreshed (one tiny
+    copy each) before every replay; the scene parameters are gathered by the kernel from the nn.Parameter
+    storages themselves (CompiledScene.param_table), so edits and optimiser steps need nothing at all, and a
+    re-allocated parameter only a refresh of the pointer table.  Changing mode, steps, resolution or the scene
+    topology needs a new capture.  Inference only (no autograd)."""
 
     def __init__(self, loop: "RenderLoop", mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None):
         self.loop, self.mode, self.degree, self.steps, self.rows = loop, mode % 8, int(degree), int(marching_steps), rows
-        rp = loop._f32_buffer("ray_positions")
-        rd = loop._f32_buffer("ray_directions")
+        rp, rd = loop._io_buffers(False)
         dev, n = rp.device, rp.shape[0]
         self.cs = compiled_for(loop.scene)
-        self.q = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+        self.q = torch.zeros(n, 4, dtype=rp.dtype, device=dev)
         self.q[:, 0] = 1.0
-        self.t = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(n, 3, dtype=rp.dtype, device=dev)
+        self._table_src = self.cs.param_table(dev)
+        self.table = None if self._table_src is None else self._table_src.clone()
         with torch.no_grad():
-            self.params = self.cs.pack_params(dev).clone()
-        cmap = loop._cmap_f32(dev) if self.mode in (6, 7) else None
+            self.params = None if self.table is not None else self.cs.pack_params(dev).clone()
+        cmap = loop._cmap(dev) if self.mode in (6, 7) else None
         flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles)
+        cs, table, params = self.cs, self.table, self.params
+
+        class _Static:          # a CompiledScene view whose scene_struct points at THIS object's static buffers
+            def __getattr__(self, name):
+                return getattr(cs, name)
+
+            def scene_struct(self, prm, device, table_=None):
+                return cs.scene_struct(params, device, table)
+
+        static = _Static()
 
         def frame():
-            return ops.render_frame(self.params, self.q, self.t, self.cs, rp, rd, loop.normals.tetra(), cmap,
+            return ops.render_frame(None, self.q, self.t, static, rp, rd, loop.normals.tetra(), cmap,
                                     self.mode, self.degree, self.steps, rows, flags, None, loop.precision)
 
         with torch.no_grad():
@@ -64,10 +76,16 @@ class CapturedFrame:
         with torch.no_grad():
             self.q.copy_(orientations)
             self.t.copy_(translations)
-            fresh = self.cs.pack_params(self.params.device)
-            if fresh.data_ptr() != getattr(self, "_seen", None):
-                self.params.copy_(fresh)          # parameters changed since the last replay
-                self._seen = fresh.data_ptr()
+            if self.table is not None:
+                cur = self.cs.param_table(self.table.device)
+                if cur is None:
+                    raise RuntimeError("CapturedFrame: a scene parameter can no longer be read in place "
+                                       "(moved off the device / changed dtype): capture again")
+                if cur is not self._table_src:    # a parameter was re-allocated: same layout, new pointers
+                    self.table.copy_(cur)
+                    self._table_src = cur
+            else:
+                self.params.copy_(self.cs.pack_params(self.params.device))
         self.graph.replay()
         return self.image
 
@@ -95,9 +113,15 @@ class RenderLoop(nn.Module):
         self.precision = precision
         self._f32_cache = {}
 
+    # cached conversions live outside the module's picklable state (copy.deepcopy / torch.save of a RenderLoop)
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_f32_cache"] = {}
+        return state
+
     def _f32_buffer(self, name: str) -> Tensor:
-        """Camera buffers as fp32 (the kernels' I/O type).  When the module was cast with
-        .to(float16) the values are the fp16-rounded ones, like the reference's cast buffers."""
+        """Camera buffer as contiguous fp32 (training frames: the backward kernels are fp32).  When the module
+        was cast with .to(float16) the values are the fp16-rounded ones, like the reference's cast buffers."""
         buf = getattr(self.camera, name)
         if buf.dtype == torch.float32 and buf.is_contiguous():
             return buf
@@ -108,12 +132,26 @@ class RenderLoop(nn.Module):
             self._f32_cache[name] = hit
         return hit[1]
 
-    def _cmap_f32(self, device) -> Tensor:
-        hit = self._f32_cache.get("cmap")
+    def _io_buffers(self, training: bool):
+        """The camera buffers the frame kernel reads: as they are (fp32 or fp16 -- no cast pass) for inference,
+        fp32 copies for training frames or exotic module dtypes."""
+        rp, rd = self.camera.ray_positions, self.camera.ray_directions
+        if not training and rp.dtype in (torch.float32, torch.float16) and rp.dtype == rd.dtype \
+                and rp.is_contiguous() and rd.is_contiguous():
+            return rp, rd
+        return self._f32_buffer("ray_positions"), self._f32_buffer("ray_directions")
+
+    def _cmap(self, device) -> Tensor:
+        """The colormap as the kernel reads it: the registered buffer itself (float64 as loaded, or whatever
+        .to(dtype) made of it) when it is on the device, else a cached device copy."""
         cm = self.shader.cyclic_cmap
-        key = (cm.data_ptr(), cm._version, str(device))
+        ok = cm.dtype in (torch.float64, torch.float32, torch.float16)
+        if ok and cm.device == torch.device(device) and cm.is_contiguous():
+            return cm
+        key = (cm.data_ptr(), cm._version, cm.dtype, str(device))
+        hit = self._f32_cache.get("cmap")
         if hit is None or hit[0] != key:
-            hit = (key, cm.to(device=device, dtype=torch.float32).contiguous())
+            hit = (key, cm.to(device=device, dtype=cm.dtype if ok else torch.float32).contiguous())
             self._f32_cache["cmap"] = hit
         return hit[1]
 
@@ -122,20 +160,26 @@ class RenderLoop(nn.Module):
         return CapturedFrame(self, mode, degree, marching_steps, rows)
 
     def forward(self, orientations: Tensor, translations: Tensor, mode: int = 0, degree: int = 1,
-                marching_steps: int = 32, rows=None, allreduce_minmax=None):
-        """-> image [N, H, W, 3].  ``rows=(r0, r1)`` renders only that pixel-row band
-        ([N, r1-r0, W, 3]); ``allreduce_minmax`` is the hook row-tiled multi-GPU rendering uses
-        for the global min/max of modes 1/2/5 (see ray_marching_amd/distributed.py)."""
+                marching_steps: int = 32, rows=None, allreduce_minmax=None, tile_order=None, tile_cost=None):
+        """-> image [N, H, W, 3] in the module's dtype (modes 6, 7: promoted with the colormap's, float64 for
+        the reference's data file).  ``rows=(r0, r1)`` renders only that pixel-row band ([N, r1-r0, W, 3]);
+        ``allreduce_minmax`` is the hook row-tiled multi-GPU rendering uses for the global min/max of modes
+        1/2/5 (see ray_marching_amd/distributed.py); ``tile_order`` / ``tile_cost``: rm_render_forward's
+        scheduling hint and per-tile cost output (include/rm_abi.h)."""
         mode = mode % 8
-        rp = self._f32_buffer("ray_positions")
-        rd = self._f32_buffer("ray_directions")
         cs = compiled_for(self.scene)
-        cmap = self._cmap_f32(rp.device) if mode in (6, 7) else None
-        image = ops.render_frame(cs.pack_params(rp.device), orientations, translations, cs, rp, rd,
+        training = torch.is_grad_enabled() and (orientations.requires_grad or translations.requires_grad
+                                                or any(p.requires_grad for p in cs.leaves))
+        rp, rd = self._io_buffers(training)
+        cmap = self._cmap(rp.device) if mode in (6, 7) else None
+        # training frames pack the parameters with torch.cat (the autograd edge back to every nn.Parameter);
+        # inference frames let the kernel gather them from the parameter storages (nothing to go stale)
+        params = cs.pack_params(rp.device) if training else None
+        image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
-                                 self.precision)
-        if mode in (6, 7) and self.shader.cyclic_cmap.dtype == torch.float64:
-            return image.double()  # reference: fp32 brightness * float64 colormap -> float64 image
+                                 self.precision, None, tile_order, tile_cost)
         out_dtype = self.camera.ray_positions.dtype
-        return image if out_dtype == torch.float32 else image.to(out_dtype)
+        if mode in (6, 7):
+            out_dtype = torch.promote_types(out_dtype, self.shader.cyclic_cmap.dtype)
+        return image if image.dtype == out_dtype else image.to(out_dtype)

@@ -36,7 +36,7 @@ constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
 int check_static(const RmScene* sc);
 
 int check_scene(const RmScene* sc) {
-  if (!sc || !sc->program || (!sc->params && sc->n_params > 0))
+  if (!sc || !sc->program || (!sc->params && !sc->param_refs && sc->n_params > 0))
     return fail(RM_E_BADARG, "scene: null program/params");
   if (sc->n_instr <= 0 || sc->n_instr > 4096 || sc->n_params < 0 || sc->n_derived < 0 ||
       sc->stack_floats < 0 || sc->n_slots < 0)
@@ -44,7 +44,7 @@ int check_scene(const RmScene* sc) {
   return check_static(sc);
 }
 
-static const int32_t* g_debug_tile_order = nullptr;   // experiment hook (rm_debug_tile_order)
+bool io_dtype_ok(int dt) { return dt == RM_DTYPE_F32 || dt == RM_DTYPE_F16; }
 
 struct Launch {
   int block;
@@ -145,14 +145,15 @@ int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
   return (int64_t)(kMaxBlocksBwd + 1) * (scene->n_params + scene->n_derived);
 }
 
-int rm_sdf_forward(const RmScene* scene, const float* points, float* dist, int64_t n, void* stream) {
+int rm_sdf_forward(const RmScene* scene, const void* points, void* dist, int64_t n, int32_t dtype, void* stream) {
   if (int e = check_scene(scene)) return e;
   if (n < 0 || (n > 0 && (!points || !dist))) return fail(RM_E_BADARG, "rm_sdf_forward: null buffer");
+  if (!io_dtype_ok(dtype)) return fail(RM_E_BADARG, "rm_sdf_forward: dtype %d is neither F32 nor F16", dtype);
   if (n == 0) return RM_OK;
   Launch L;
   if (int e = pick_launch(rm::k_sdf_fwd<G>, *scene, false, 256, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
-  rm::k_sdf_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, dist, n);
+  rm::k_sdf_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, dist, n, dtype);
   return launched("k_sdf_fwd");
 }
 
@@ -172,15 +173,16 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
 #endif
 }
 
-int rm_march_forward(const RmScene* scene, const float* pos, const float* dirs, float* out_pos, float* traj,
-                     int32_t* nexec, int64_t n, int32_t steps, int32_t flags, void* stream) {
+int rm_march_forward(const RmScene* scene, const void* pos, const void* dirs, void* out_pos, float* traj,
+                     int32_t* nexec, int64_t n, int32_t steps, int32_t flags, int32_t dtype, void* stream) {
   if (int e = check_scene(scene)) return e;
   if (n < 0 || steps < 0 || (n > 0 && (!pos || !dirs || !out_pos))) return fail(RM_E_BADARG, "rm_march_forward: bad args");
+  if (!io_dtype_ok(dtype)) return fail(RM_E_BADARG, "rm_march_forward: dtype %d is neither F32 nor F16", dtype);
   if (n == 0) return RM_OK;
   Launch L;
   if (int e = pick_launch(rm::k_march_fwd<G>, *scene, false, 256, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
-  rm::k_march_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, pos, dirs, out_pos, traj, nexec, n, steps, flags);
+  rm::k_march_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, pos, dirs, out_pos, traj, nexec, n, steps, flags, dtype);
   return launched("k_march_fwd");
 }
 
@@ -203,15 +205,16 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
 #endif
 }
 
-int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const float* coords, float* normals,
-                       float* laplacian, int64_t n, void* stream) {
+int rm_normals_forward(const RmScene* scene, const RmTetra* tetra, const void* coords, void* normals,
+                       void* laplacian, int64_t n, int32_t dtype, void* stream) {
   if (int e = check_scene(scene)) return e;
   if (!tetra || n < 0 || (n > 0 && (!coords || !normals || !laplacian))) return fail(RM_E_BADARG, "rm_normals_forward: bad args");
+  if (!io_dtype_ok(dtype)) return fail(RM_E_BADARG, "rm_normals_forward: dtype %d is neither F32 nor F16", dtype);
   if (n == 0) return RM_OK;
   Launch L;
   if (int e = pick_launch(rm::k_normals_fwd<G>, *scene, false, 256, &L)) return e;
   int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocks);
-  rm::k_normals_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, normals, laplacian, n);
+  rm::k_normals_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, normals, laplacian, n, dtype);
   return launched("k_normals_fwd");
 }
 
@@ -233,10 +236,11 @@ int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float*
 #endif
 }
 
-int rm_camera_forward(const RmCamera* cam, const float* orientation, const float* translation, float* out_pos,
-                      float* out_dirs, float* out_frames, void* stream) {
+int rm_camera_forward(const RmCamera* cam, const void* orientation, const void* translation, void* out_pos,
+                      void* out_dirs, void* out_frames, void* stream) {
   if (!cam || !cam->ray_positions || !cam->ray_directions || !orientation || !translation || !out_pos || !out_dirs)
     return fail(RM_E_BADARG, "rm_camera_forward: null buffer");
+  if (!io_dtype_ok(cam->dtype)) return fail(RM_E_BADARG, "rm_camera_forward: camera dtype %d is neither F32 nor F16", cam->dtype);
   if (cam->num_cameras <= 0 || cam->num_cameras > 256 || cam->height <= 0 || cam->width <= 0)
     return fail(RM_E_BADARG, "rm_camera_forward: bad camera shape");
   int64_t n = (int64_t)cam->num_cameras * cam->height * cam->width;
@@ -245,51 +249,61 @@ int rm_camera_forward(const RmCamera* cam, const float* orientation, const float
   return launched("k_camera_fwd");
 }
 
-static int check_render(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
-                        const float* translation, int32_t steps, int32_t row_begin, int32_t row_end) {
+static int check_render(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const void* orientation,
+                        const void* translation, int32_t steps, int32_t row_begin, int32_t row_end) {
   if (int e = check_scene(scene)) return e;
   if (!cam || !tetra || !cam->ray_positions || !cam->ray_directions || !orientation || !translation)
     return fail(RM_E_BADARG, "render: null camera / pose");
+  if (!io_dtype_ok(cam->dtype)) return fail(RM_E_BADARG, "render: camera dtype %d is neither F32 nor F16", cam->dtype);
   if (cam->num_cameras <= 0 || cam->height <= 0 || cam->width <= 0) return fail(RM_E_BADARG, "render: bad camera shape");
   if (steps < 0 || row_begin < 0 || row_end > cam->height || row_begin >= row_end)
     return fail(RM_E_BADARG, "render: bad steps/rows (%d, [%d,%d) of %d)", steps, row_begin, row_end, cam->height);
   return RM_OK;
 }
 
-int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
-                      const float* translation, float* image, float* p_final, float* traj, int32_t* nexec,
-                      uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
-                      int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, void* stream) {
+static int64_t wave_tile_count(int32_t num_cameras, int32_t rows, int32_t width, int32_t flags) {
+  return (flags & RM_FLAG_TILE8X8) ? (int64_t)num_cameras * ((width + 7) >> 3) * ((rows + 7) >> 3)
+                                   : ((int64_t)num_cameras * rows * width + 63) / 64;
+}
+
+int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t flags) {
+  if (num_cameras <= 0 || rows <= 0 || width <= 0) return 0;
+  return wave_tile_count(num_cameras, rows, width, flags);
+}
+
+int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const void* orientation,
+                      const void* translation, void* image, int32_t image_dtype, float* first_pass, float* p_final,
+                      float* traj, int32_t* nexec, uint32_t* minmax, const void* cmap, int32_t cmap_size,
+                      int32_t cmap_dtype, int32_t mode, int32_t degree, int32_t steps, int32_t row_begin,
+                      int32_t row_end, int32_t flags, const int32_t* tile_order, int32_t* tile_cost, void* stream) {
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
   if (!image) return fail(RM_E_BADARG, "rm_render_forward: null image");
   if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_render_forward: mode %d not in 0..7", mode);
-  bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
-  if (global && !minmax) return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a minmax buffer", mode);
-  if ((mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN) && (!cmap || cmap_size <= 0))
-    return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a colormap", mode);
+  const bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
+  const bool mapped = (mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
+  if (global && (!minmax || !first_pass))
+    return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a minmax workspace and a first_pass buffer", mode);
+  if (mapped && (!cmap || cmap_size <= 0 || cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64))
+    return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a colormap (F32, F16 or F64)", mode);
+  if (!(io_dtype_ok(image_dtype) || (image_dtype == RM_DTYPE_F64 && mapped)))
+    return fail(RM_E_BADARG, "rm_render_forward: image dtype %d (F64 only for modes 6, 7)", image_dtype);
   rm::RenderArgs a;
   memset(&a, 0, sizeof(a));
   a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
   a.orientation = orientation; a.translation = translation;
-  a.image = image; a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.minmax = minmax;
-  a.cmap = cmap; a.cmap_size = cmap_size;
+  a.image = image; a.image_dtype = image_dtype; a.first_pass = first_pass;
+  a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.minmax = minmax;
+  a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype;
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
-  a.tile_order = g_debug_tile_order;
+  a.tile_order = tile_order; a.tile_cost = tile_cost;
   Launch L;
   if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
-  int64_t wave_tiles;
-  {
-    const int W = cam->width, rows = row_end - row_begin;
-    wave_tiles = (flags & RM_FLAG_TILE8X8) ? (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3)
-                                           : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
-  }
+  const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   return launched("k_render_fwd");
 }
-
-int rm_debug_tile_order(const int32_t* order) { g_debug_tile_order = order; return RM_OK; }
 
 int rm_minmax_init(uint32_t* minmax, void* stream) {
   if (!minmax) return fail(RM_E_BADARG, "rm_minmax_init: null");
@@ -309,20 +323,23 @@ int rm_minmax_encode(const float* lohi, uint32_t* minmax, void* stream) {
   return launched("k_minmax_encode");
 }
 
-int rm_shade_finish(float* image, int64_t n_pixels, const uint32_t* minmax, int32_t mode, void* stream) {
-  if (!image || !minmax || n_pixels < 0) return fail(RM_E_BADARG, "rm_shade_finish: bad args");
+int rm_shade_finish(const float* first_pass, void* image, int32_t image_dtype, int64_t n_pixels, const uint32_t* minmax,
+                    int32_t mode, void* stream) {
+  if (!first_pass || !image || !minmax || n_pixels < 0) return fail(RM_E_BADARG, "rm_shade_finish: bad args");
+  if (!io_dtype_ok(image_dtype) || (image_dtype != RM_DTYPE_F32 && (const void*)first_pass == (const void*)image))
+    return fail(RM_E_BADARG, "rm_shade_finish: image dtype %d (in place only for F32)", image_dtype);
   if (!(mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN))
     return fail(RM_E_BADARG, "rm_shade_finish: mode %d has no second pass", mode);
   if (n_pixels == 0) return RM_OK;
   int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
-  rm::k_shade_finish<<<grid, 256, 0, (hipStream_t)stream>>>(image, n_pixels, minmax, mode);
+  rm::k_shade_finish<<<grid, 256, 0, (hipStream_t)stream>>>(first_pass, image, image_dtype, n_pixels, minmax, mode);
   return launched("k_shade_finish");
 }
 
 int rm_shade_forward(const float* px_coords, const float* orientation, const float* frames, const float* dirs,
-                     const float* coords, const float* normals, const float* lap, const float* dist, float* image,
-                     uint32_t* minmax, const float* cmap, int32_t cmap_size, int32_t mode, int32_t degree,
-                     int64_t n_pixels, int64_t pixels_per_camera, void* stream) {
+                     const float* coords, const float* normals, const float* lap, const float* dist, void* image,
+                     int32_t image_dtype, uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype,
+                     int32_t mode, int32_t degree, int64_t n_pixels, int64_t pixels_per_camera, void* stream) {
   if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_shade_forward: mode %d not in 0..7", mode);
   if (!image || n_pixels < 0 || pixels_per_camera <= 0) return fail(RM_E_BADARG, "rm_shade_forward: bad args");
   const bool need_n = (mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL || mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
@@ -333,9 +350,12 @@ int rm_shade_forward(const float* px_coords, const float* orientation, const flo
       (mode == RM_MODE_DISTANCE && (!px_coords || !coords)) || (mode == RM_MODE_PROXIMITY && !dist) ||
       (mode == RM_MODE_LAPLACIAN && !lap) || (mode == RM_MODE_VIGNETTE && !frames) || (global && !minmax))
     return fail(RM_E_BADARG, "rm_shade_forward: an input required by mode %d is null", mode);
+  if (need_q && (cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64)) return fail(RM_E_BADARG, "rm_shade_forward: colormap dtype %d", cmap_dtype);
+  if (global ? image_dtype != RM_DTYPE_F32 : !(io_dtype_ok(image_dtype) || (image_dtype == RM_DTYPE_F64 && need_q)))
+    return fail(RM_E_BADARG, "rm_shade_forward: image dtype %d not valid for mode %d", image_dtype, mode);
   if (n_pixels == 0) return RM_OK;
   rm::ShadeArgs a{px_coords, orientation, frames, dirs, coords, normals, lap, dist, image, minmax, cmap,
-                  cmap_size, mode, degree, n_pixels, pixels_per_camera};
+                  cmap_size, mode, degree, n_pixels, pixels_per_camera, image_dtype, cmap_dtype};
   int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
   rm::k_shade_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return launched("k_shade_fwd");
@@ -361,6 +381,7 @@ int rm_camera_backward(const RmCamera* cam, const float* orientation, const floa
                        int32_t row_end, void* stream) {
   if (!cam || !cam->ray_positions || !cam->ray_directions || !orientation || !partials || (!grad_pos && !grad_dirs))
     return fail(RM_E_BADARG, "rm_camera_backward: null buffer");
+  if (cam->dtype != RM_DTYPE_F32) return fail(RM_E_BADARG, "rm_camera_backward: fp32 camera buffers only");
   if (cam->num_cameras <= 0 || cam->num_cameras > 1024 || row_begin < 0 || row_end > cam->height || row_begin >= row_end)
     return fail(RM_E_BADARG, "rm_camera_backward: bad camera shape / rows");
   const int bpc = RM_CAMERA_BWD_BLOCKS;
@@ -381,6 +402,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   return fail(RM_E_BADARG, "rm_render_backward: this specialised library was built forward-only");
 #else
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
+  if (cam->dtype != RM_DTYPE_F32) return fail(RM_E_BADARG, "rm_render_backward: fp32 camera buffers only");
   if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL))
     return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (use modes 0 or 4)", mode);
   if (!p_final || !grad_image || !partials || (steps > 0 && !traj)) return fail(RM_E_BADARG, "rm_render_backward: null buffer");
@@ -434,6 +456,7 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_SMOOTH_BEGIN: depth_b += 2; break;
       case RM_OP_UNION_END: case RM_OP_SMOOTH_END:
         if (a1 <= 0 || a0 < 0 || a0 + a1 > n_slots) return fail(RM_E_PROGRAM, "instr %d: slots out of range", i);
+        if (op == RM_OP_SMOOTH_END && a1 >= 512) return fail(RM_E_PROGRAM, "instr %d: smooth union of %d >= 512 children", i, a1);
         depth_f -= (op == RM_OP_UNION_END) ? 1 : 0; depth_b -= 2;
         values++;
         break;

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../include/rm_abi.h"
+#include "rm_math.h"
 
 namespace rm {
 
@@ -66,25 +67,72 @@ RM_DEV float rm_sqrt(float x) {
   return r;
 #endif
 }
-// exp / log of the smooth union (torch.logsumexp).  ATen's CPU kernels use Sleef's 1-ulp expf/logf, ocml's
-// are 1 ulp too but not the same ulp, so this node is compared within the 1e-5 / 1e-4 bar, not bitwise
-// (DESIGN.md 4).  The hardware forms -- v_exp_f32(x log2 e), v_log_f32(x) ln 2: 2 instructions instead of
-// ~14 and ~20 -- are ~2 ulp: measured 12 % faster on the 32-primitive scene and 9 % on the config-4 step,
-// but the tetrahedral normals amplify the extra ulp to 1.0014e-5 on one pixel of the closed-scene-1
-// fixture (5.1e-6 with ocml), over the 1e-5 bar.  They are therefore part of the opt-in fast build only.
+// exp / log / pow / atan2 (rm_math.h).  torch's CPU exp and log are MKL VML (closed source, and the bits depend
+// on the host CPU), so the exact build computes the correctly rounded value through fp64; pow and atan2 are
+// Sleef's u10 algorithms restated, bit-identical with torch.  The opt-in fast build takes the hardware forms
+// (v_exp_f32 / v_log_f32, ~2 ulp) and ocml's powf / atan2f.
 RM_DEV float rm_exp(float x) {
 #if defined(RM_FAST_MATH)
   return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
 #else
-  return expf(x);
+  return exp_f64path(x);
 #endif
 }
 RM_DEV float rm_log(float x) {
 #if defined(RM_FAST_MATH)
   return __builtin_amdgcn_logf(x) * 0.693147180559945309417f;
 #else
-  return logf(x);
+  return log_f64path(x);
 #endif
+}
+RM_DEV float rm_pow(float x, float y) {
+#if defined(RM_FAST_MATH)
+  return powf(x, y);
+#else
+  return sleef_powf(x, y);
+#endif
+}
+RM_DEV float rm_atan2(float y, float x) {
+#if defined(RM_FAST_MATH)
+  return atan2f(y, x);
+#else
+  return sleef_atan2f(y, x);
+#endif
+}
+// sum_{i<n} e(i) with the association ATen's CPU sum kernel uses for a contiguous inner reduction of n fp32
+// values (aten/src/ATen/native/cpu/SumKernel.cpp, measured against torch.sum in oracle tests): fewer than 8
+// elements -> four interleaved partial sums (row_sum, ilp_factor 4), elements past the last full group of four
+// going to the first; 8 or more -> 8-lane vector partial sums, again four interleaved, the scalar tail first
+// and the 8 lanes added one after the other.  n < 512 (beyond that the kernel's cascade levels start; the host
+// compiler rejects such unions).  torch.logsumexp sums its exp() terms with this kernel (transformations.py:70),
+// and a plain left-to-right sum differs from it in the last bit for most inputs once n > 4.
+template <class F>
+RM_DEV float aten_inner_sum(int n, F e) {
+  if (n < 8) {
+    if (n < 4) {
+      float s = 0.0f;
+      for (int i = 0; i < n; ++i) s = s + e(i);
+      return s;
+    }
+    float p0 = e(0), p1 = e(1), p2 = e(2), p3 = e(3);
+    for (int i = 4; i < n; ++i) p0 = p0 + e(i);
+    return ((p0 + p1) + p2) + p3;
+  }
+  const int nv = n >> 3, k = nv >> 2;
+  float fin = 0.0f;
+  for (int i = nv * 8; i < n; ++i) fin = fin + e(i);
+  for (int l = 0; l < 8; ++l) {
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    for (int i = 0; i < k; ++i) {
+      p0 = p0 + e((4 * i) * 8 + l);
+      p1 = p1 + e((4 * i + 1) * 8 + l);
+      p2 = p2 + e((4 * i + 2) * 8 + l);
+      p3 = p3 + e((4 * i + 3) * 8 + l);
+    }
+    for (int i = 4 * k; i < nv; ++i) p0 = p0 + e(i * 8 + l);
+    fin = fin + (((p0 + p1) + p2) + p3);
+  }
+  return fin;
 }
 // ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
 RM_DEV float norm3(V3 a) { return rm_sqrt(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
@@ -284,8 +332,7 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       float m = -__builtin_inff();
       for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
       float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
-      float sum = 0.0f;
-      for (int i = 0; i < a1; ++i) sum = sum + rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm);
+      float sum = aten_inner_sum(a1, [&](int i) { return rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm); });
       s.d = (rm_log(sum) + mm) / nk;
     } break;
     case RM_OP_ROUND:
@@ -447,8 +494,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       float m = -__builtin_inff();
       for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
       float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
-      float sum = 0.0f;
-      for (int i = 0; i < a1; ++i) sum = sum + rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm);
+      float sum = aten_inner_sum(a1, [&](int i) { return rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm); });
       float L = rm_log(sum) + mm;
       s.gframe = s.g;
       s.fval = L;
@@ -641,6 +687,7 @@ struct Scene {
 // Derived constants (capsule AB and AB/|AB|^2, primitives.py:52-54) are
 // computed once per block instead of once per evaluation.
 // --------------------------------------------------------------------------
+RM_DEV float ld_t(const void* base, int64_t i, int dt);
 // Bounding sphere (centre, radius) of the surface of the subtree encoded by instructions [begin, end),
 // in the frame in which that subtree is evaluated: subtree(p) >= |p - c| - R for every p.  R = +inf
 // when no finite bound is known (plane, strongly non-unit affine quaternion, non-positive blend_k, odd
@@ -791,8 +838,20 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
 }
 
 // LDS staging of the scene block: raw parameters, then derived constants.
+// raw parameter block -> LDS: from the packed fp32 array, or gathered from the parameter tensors themselves
+RM_DEV void stage_params(const RmScene& sc, float* s_params, int n_params) {
+  if (sc.param_refs) {
+    for (int i = threadIdx.x; i < n_params; i += blockDim.x) {
+      const RmParamRef r = sc.param_refs[i];
+      s_params[i] = ld_t(r.base, r.elem, r.dtype);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_params; i += blockDim.x) s_params[i] = sc.params[i];
+  }
+}
+
 RM_DEV void stage_scene(const RmScene& sc, float* s_params, int4* s_prog) {
-  for (int i = threadIdx.x; i < sc.n_params; i += blockDim.x) s_params[i] = sc.params[i];
+  stage_params(sc, s_params, sc.n_params);
   const int4* gprog = reinterpret_cast<const int4*>(sc.program);
   for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) s_prog[i] = gprog[i];
   __syncthreads();
@@ -816,6 +875,26 @@ RM_DEV V3 load3(const float* base, int64_t i) {
 RM_DEV void store3(float* base, int64_t i, V3 v) {
   float* q = base + 3 * i;
   q[0] = v.x; q[1] = v.y; q[2] = v.z;
+}
+
+// typed I/O (RM_DTYPE_*): `dt` is a kernel argument, hence wave-uniform: a scalar branch per access
+RM_DEV float ld_t(const void* base, int64_t i, int dt) {
+  return (dt == RM_DTYPE_F16) ? (float)static_cast<const _Float16*>(base)[i] : static_cast<const float*>(base)[i];
+}
+RM_DEV void st_t(void* base, int64_t i, float v, int dt) {
+  if (dt == RM_DTYPE_F16) static_cast<_Float16*>(base)[i] = (_Float16)v;          // round to nearest even, like .to(float16)
+  else if (dt == RM_DTYPE_F64) static_cast<double*>(base)[i] = (double)v;
+  else static_cast<float*>(base)[i] = v;
+}
+RM_DEV V3 load3_t(const void* base, int64_t i, int dt) {
+  if (dt == RM_DTYPE_F16) {
+    const _Float16* q = static_cast<const _Float16*>(base) + 3 * i;
+    return V3{(float)q[0], (float)q[1], (float)q[2]};
+  }
+  return load3(static_cast<const float*>(base), i);
+}
+RM_DEV void store3_t(void* base, int64_t i, V3 v, int dt) {
+  st_t(base, 3 * i, v.x, dt); st_t(base, 3 * i + 1, v.y, dt); st_t(base, 3 * i + 2, v.z, dt);
 }
 
 struct Tetra {

@@ -72,7 +72,7 @@ struct StaticCfg {
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool = false) {
     // the parameter block is still staged through LDS (raw + derived), the program is not
     float* s_params = smem;
-    for (int i = threadIdx.x; i < Code::n_params; i += blockDim.x) s_params[i] = sc.params[i];
+    stage_params(sc, s_params, Code::n_params);
     __syncthreads();
     auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
     derive_constants(ins, Code::n, s_params);
@@ -137,7 +137,7 @@ RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float*
 // scene(query) forward / backward
 // ---------------------------------------------------------------------------
 template <class Cfg>
-__global__ void __launch_bounds__(256) k_sdf_fwd(RmScene sc, const float* __restrict__ pts, float* __restrict__ dist, int64_t n) {
+__global__ void __launch_bounds__(256) k_sdf_fwd(RmScene sc, const void* __restrict__ pts, void* __restrict__ dist, int64_t n, int dt) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
@@ -145,8 +145,8 @@ __global__ void __launch_bounds__(256) k_sdf_fwd(RmScene sc, const float* __rest
     int64_t i = tile * blockDim.x + threadIdx.x;
     bool live = i < n;
     int64_t ic = live ? i : n - 1;
-    float d = scene.eval(load3(pts, ic));
-    if (live) dist[i] = d;
+    float d = scene.eval(load3_t(pts, ic, dt));
+    if (live) st_t(dist, i, d, dt);
   }
 }
 
@@ -248,9 +248,9 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const float* __restrict__ pos, const float* __restrict__ dirs,
-                            float* __restrict__ out, float* __restrict__ traj, int32_t* __restrict__ nexec_out,
-                            int64_t n, int steps, int flags) {
+__global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const void* __restrict__ pos, const void* __restrict__ dirs,
+                            void* __restrict__ out, float* __restrict__ traj, int32_t* __restrict__ nexec_out,
+                            int64_t n, int steps, int flags, int dt) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
   int64_t ntiles = (n + blockDim.x - 1) / blockDim.x;
@@ -259,9 +259,9 @@ __global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const float* __re
     bool live = i < n;
     int64_t ic = live ? i : n - 1;
     int nexec;
-    V3 p = march(scene, load3(pos, ic), load3(dirs, ic), steps, flags & RM_FLAG_EARLY_OUT, traj, n, ic, live, nexec);
+    V3 p = march(scene, load3_t(pos, ic, dt), load3_t(dirs, ic, dt), steps, flags & RM_FLAG_EARLY_OUT, traj, n, ic, live, nexec);
     if (live) {
-      store3(out, i, p);
+      store3_t(out, i, p, dt);
       if (nexec_out) nexec_out[i] = nexec;
     }
   }
@@ -344,8 +344,8 @@ __global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __re
 // normals
 // ---------------------------------------------------------------------------
 template <class Cfg>
-__global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, const float* __restrict__ pts, float* __restrict__ nrm,
-                              float* __restrict__ lap, int64_t n) {
+__global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, const void* __restrict__ pts, void* __restrict__ nrm,
+                              void* __restrict__ lap, int64_t n, int dt) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(sc, rm_smem, store);
   Tetra T = load_tetra(tetra);
@@ -354,13 +354,13 @@ __global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, 
     int64_t i = tile * blockDim.x + threadIdx.x;
     bool live = i < n;
     int64_t ic = live ? i : n - 1;
-    V3 p = load3(pts, ic);
+    V3 p = load3_t(pts, ic, dt);
     float c = scene.eval(p);
     V3 nn; float ll;
     normals_forward(scene, T, p, c, nn, ll);
     if (live) {
-      store3(nrm, i, nn);
-      lap[i] = ll;
+      store3_t(nrm, i, nn, dt);
+      st_t(lap, i, ll, dt);
     }
   }
 }
@@ -434,17 +434,19 @@ struct RenderArgs {
   RmScene scene;
   RmCamera cam;
   RmTetra tetra;
-  const float* orientation;  // [N,4]
-  const float* translation;  // [N,3]
-  float* image;              // [N,rows,W,3]
+  const void* orientation;   // [N,4]  element type cam.dtype
+  const void* translation;   // [N,3]
+  void* image;               // [N,rows,W,3] of image_dtype
+  float* first_pass;         // modes 1, 2, 5: fp32 [N,rows,W,3] un-normalised values
   float* p_final;            // nullable
   float* traj;               // nullable [steps, R, 3]
   int32_t* nexec;            // nullable
   uint32_t* minmax;          // nullable
-  const float* cmap;         // nullable
-  int32_t cmap_size;
+  const void* cmap;          // nullable, [cmap_size,3] of cmap_dtype
+  int32_t cmap_size, cmap_dtype, image_dtype;
   int32_t mode, degree, steps, row_begin, row_end, flags;
   const int32_t* tile_order; // nullable: position in the dealing order -> wave tile (longest-first schedules)
+  int32_t* tile_cost;        // nullable out: march steps executed by the wave of each tile
   // backward only
   const float* grad_image;
   float* partials;
@@ -561,24 +563,53 @@ RM_DEV void next_wave_tile(const RenderArgs& a, int64_t ntiles, TileCursor& c) {
   }
 }
 
-RM_DEV Pose load_pose(const float* orientation, const float* translation, int cam) {
+RM_DEV Pose load_pose(const void* orientation, const void* translation, int cam, int dt = RM_DTYPE_F32) {
   Pose ps;
-  ps.w = orientation[4 * cam];
-  ps.qv = mk3(orientation[4 * cam + 1], orientation[4 * cam + 2], orientation[4 * cam + 3]);
-  ps.t = mk3(translation[3 * cam], translation[3 * cam + 1], translation[3 * cam + 2]);
+  ps.w = ld_t(orientation, 4 * cam, dt);
+  ps.qv = mk3(ld_t(orientation, 4 * cam + 1, dt), ld_t(orientation, 4 * cam + 2, dt), ld_t(orientation, 4 * cam + 3, dt));
+  ps.t = load3_t(translation, cam, dt);
   return ps;
 }
 
+// One shaded pixel: rgb, or -- tangent / spin shaders -- a brightness and a colormap row whose product is taken
+// in the colormap's own type when the pixel is stored (store_shaded).
+struct Shaded {
+  V3 rgb;
+  float bright;
+  int idx;      // >= 0: colour = bright * cmap[idx]
+};
+RM_DEV Shaded plain(V3 rgb) { return Shaded{rgb, 0.0f, -1}; }
+
 // angle_colouring / domain_colouring (shader.py:92-118)
-RM_DEV V3 domain_colour(float re, float im, const float* cmap, int size, int degree) {
+RM_DEV Shaded domain_colour(float re, float im, int size, int degree) {
   const float tau = 6.283185307179586f;
-  float x = (((atan2f(im, re) / tau) + 0.5f) * (float)degree) * (float)size;
+  float x = (((rm_atan2(im, re) / tau) + 0.5f) * (float)degree) * (float)size;
   long long idx = (long long)floorf(x);
   long long m = idx % size;
   if (m < 0) m += size;
   float bright = rm_sqrt(re * re + im * im);
   if (!(x == x)) { m = 0; bright = x; }  // NaN normal: propagate NaN instead of indexing with it
-  return mk3(bright * cmap[3 * m], bright * cmap[3 * m + 1], bright * cmap[3 * m + 2]);
+  return Shaded{mk3(0.0f, 0.0f, 0.0f), bright, (int)m};
+}
+
+// brightness.mul(colours) (shader.py:118): fp32 brightness times a float64 colormap row is a float64 product
+// (type promotion), times an fp32 / fp16 row a product in that type.
+RM_DEV void store_shaded(void* image, int image_dt, int64_t li, const Shaded& s, const void* cmap, int cmap_dt) {
+  if (s.idx < 0) { store3_t(image, li, s.rgb, image_dt); return; }
+  if (cmap_dt == RM_DTYPE_F64) {
+    const double* c = static_cast<const double*>(cmap) + 3 * (int64_t)s.idx;
+    const double b = (double)s.bright;
+    const double r0 = b * c[0], r1 = b * c[1], r2 = b * c[2];
+    if (image_dt == RM_DTYPE_F64) {
+      double* o = static_cast<double*>(image) + 3 * li;
+      o[0] = r0; o[1] = r1; o[2] = r2;
+    } else {
+      store3_t(image, li, mk3((float)r0, (float)r1, (float)r2), image_dt);
+    }
+    return;
+  }
+  const V3 c = load3_t(cmap, s.idx, cmap_dt);
+  store3_t(image, li, mk3(s.bright * c.x, s.bright * c.y, s.bright * c.z), image_dt);
 }
 
 struct ShadeIn {
@@ -590,35 +621,35 @@ struct ShadeIn {
 
 // One pixel of Shader.forward (shader.py:190-263).  Modes 1, 2, 5 return the
 // un-normalised value; rm_shade_finish applies the global min/max.
-RM_DEV V3 shade_pixel(int mode, const ShadeIn& s, const float* cmap, int cmap_size, int degree) {
+RM_DEV Shaded shade_pixel(int mode, const ShadeIn& s, int cmap_size, int degree) {
   switch (mode) {
     case RM_MODE_LAMBERTIAN: {  // shader.py:16-20
       float c = t_clamp(-dot_seq(s.v, s.n), 0.0f, 1.0f);
-      return mk3(c, c, c);
+      return plain(mk3(c, c, c));
     }
     case RM_MODE_DISTANCE: {    // shader.py:27-33
-      float l = logf(t_clamp(norm3(s.o - s.p), 1e-2f, __builtin_inff()));
-      return mk3(l, l, l);
+      float l = rm_log(t_clamp(norm3(s.o - s.p), 1e-2f, __builtin_inff()));
+      return plain(mk3(l, l, l));
     }
     case RM_MODE_PROXIMITY: {   // shader.py:45-50
-      float l = logf(t_clamp(s.dist, 1e-2f, __builtin_inff()));
-      return mk3(l, l, l);
+      float l = rm_log(t_clamp(s.dist, 1e-2f, __builtin_inff()));
+      return plain(mk3(l, l, l));
     }
     case RM_MODE_VIGNETTE: {    // shader.py:62-66
       float d = dot_seq(s.v, s.col2);
       float c = (d * d) * d;
-      return mk3(c, c, c);
+      return plain(mk3(c, c, c));
     }
     case RM_MODE_NORMAL:        // shader.py:73-74
-      return mk3(t_clamp(fabsf(s.n.x), 0.0f, 1.0f), t_clamp(fabsf(s.n.y), 0.0f, 1.0f),
-                 t_clamp(fabsf(s.n.z), 0.0f, 1.0f));
+      return plain(mk3(t_clamp(fabsf(s.n.x), 0.0f, 1.0f), t_clamp(fabsf(s.n.y), 0.0f, 1.0f),
+                       t_clamp(fabsf(s.n.z), 0.0f, 1.0f)));
     case RM_MODE_LAPLACIAN:     // shader.py:81-89
-      return mk3(s.lap, s.lap, s.lap);
+      return plain(mk3(s.lap, s.lap, s.lap));
     case RM_MODE_TANGENT: {     // shader.py:125-150
       float c = dot_seq(s.n, s.v);
       V3 tg = mk3((c * s.v.x) * -1.0f + s.n.x, (c * s.v.y) * -1.0f + s.n.y, (c * s.v.z) * -1.0f + s.n.z);
       V3 pr = qrot(tg, s.qw, neg(s.qv));
-      return domain_colour(pr.x, pr.y, cmap, cmap_size, degree);
+      return domain_colour(pr.x, pr.y, cmap_size, degree);
     }
     default: {                  // RM_MODE_SPIN, shader.py:157-171: (0,n) * conj(q)
       float q0 = s.qw, q1 = -s.qv.x, q2 = -s.qv.y, q3 = -s.qv.z;
@@ -629,7 +660,7 @@ RM_DEV V3 shade_pixel(int mode, const ShadeIn& s, const float* cmap, int cmap_si
       float r3 = ((p0 * q3 + p1 * q2) + p3 * q0) - p2 * q1;
       float re = r0 * r0 - ((r1 * r1 + r2 * r2) + r3 * r3);
       float im = (norm3(mk3(r1, r2, r3)) * r0) * 2.0f;
-      return domain_colour(im, re, cmap, cmap_size, degree);   // (imag, real) swapped as in the reference
+      return domain_colour(im, re, cmap_size, degree);   // (imag, real) swapped as in the reference
     }
   }
 }
@@ -651,11 +682,12 @@ RM_DEV void fold_minmax(uint32_t* minmax, float lo, float hi, bool saw_nan) {
 // Standalone Shader.forward over tensors (any of the inputs a mode does not read may be null).
 struct ShadeArgs {
   const float *px, *orientation, *frames, *dirs, *coords, *normals, *lap, *dist;
-  float* image;
+  void* image;
   uint32_t* minmax;
-  const float* cmap;
+  const void* cmap;
   int32_t cmap_size, mode, degree;
   int64_t n, per_camera;
+  int32_t image_dtype, cmap_dtype;
 };
 
 __global__ void k_shade_fwd(ShadeArgs a) {
@@ -677,8 +709,9 @@ __global__ void k_shade_fwd(ShadeArgs a) {
     s.qw = a.orientation ? a.orientation[4 * cam] : 1.0f;
     s.qv = a.orientation ? mk3(a.orientation[4 * cam + 1], a.orientation[4 * cam + 2], a.orientation[4 * cam + 3]) : z;
     s.col2 = a.frames ? mk3(a.frames[9 * cam + 2], a.frames[9 * cam + 5], a.frames[9 * cam + 8]) : z;
-    V3 out = shade_pixel(a.mode, s, a.cmap, a.cmap_size, a.degree);
-    store3(a.image, i, out);
+    const Shaded sh = shade_pixel(a.mode, s, a.cmap_size, a.degree);
+    const V3 out = sh.rgb;
+    store_shaded(a.image, a.image_dtype, i, sh, a.cmap, a.cmap_dtype);
     if (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY) {
       saw_nan |= (out.x != out.x);
       lo = fminf(lo, out.x); hi = fmaxf(hi, out.x);
@@ -707,10 +740,10 @@ RM_DEV TileRays load_tile_rays(const RenderArgs& a, int64_t tile) {
   if (!r.live) { cam = 0; row = 0; col = 0; }
   r.li = ((int64_t)cam * rows + row) * W + col;                          // index in the band outputs
   int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;       // index in the camera buffers
-  r.ps = load_pose(a.orientation, a.translation, cam);
+  r.ps = load_pose(a.orientation, a.translation, cam, a.cam.dtype);
   // PinholeCamera.forward (ray_marching.py:58-62)
-  r.o = qrot(load3(a.cam.ray_positions, gi), r.ps.w, r.ps.qv) + r.ps.t;
-  r.v = qrot(load3(a.cam.ray_directions, gi), r.ps.w, r.ps.qv);
+  r.o = qrot(load3_t(a.cam.ray_positions, gi, a.cam.dtype), r.ps.w, r.ps.qv) + r.ps.t;
+  r.v = qrot(load3_t(a.cam.ray_directions, gi, a.cam.dtype), r.ps.w, r.ps.qv);
   return r;
 }
 
@@ -735,9 +768,12 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
     float w = r.ps.w, x = r.ps.qv.x, y = r.ps.qv.y, z = r.ps.qv.z;
     si.col2 = mk3(2.0f * (w * y + x * z), 2.0f * (y * z - w * x), ((w * w - x * x) - y * y) + z * z);
   }
-  V3 out = shade_pixel(mode, si, a.cmap, a.cmap_size, a.degree);
+  const Shaded sh = shade_pixel(mode, si, a.cmap_size, a.degree);
+  const V3 out = sh.rgb;
+  const bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
   if (r.live) {
-    store3(a.image, r.li, out);
+    if (global) store3(a.first_pass, r.li, out);          // rm_shade_finish normalises into `image`
+    else store_shaded(a.image, a.image_dtype, r.li, sh, a.cmap, a.cmap_dtype);
     if (a.p_final) store3(a.p_final, r.li, p);
     if (a.nexec) a.nexec[r.li] = nexec;
     if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
@@ -766,6 +802,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     TileRays r = load_tile_rays(a, tile);
     int nexec;
     V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec);
+    if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tile] = nexec;     // nexec is wave-uniform
     finish_tile(a, scene, T, r, p, nexec, mm);
   }
   if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
@@ -773,19 +810,19 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
 }
 
 // second pass for the globally normalised shaders
-__global__ void k_shade_finish(float* __restrict__ image, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
+__global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
   float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
   if (minmax[2]) { lo = __builtin_nanf(""); hi = lo; }
   const float gamma = (float)(1.0 / 2.33);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float x = image[3 * i];
+    float x = src[3 * i];
     float y;
     if (mode == RM_MODE_LAPLACIAN) {   // shader.py:83-88
-      y = powf(t_clamp((((x / hi) * -1.0f) + 1.0f) / 2.0f, 0.0f, 1.0f), gamma);
+      y = rm_pow(t_clamp((((x / hi) * -1.0f) + 1.0f) / 2.0f, 0.0f, 1.0f), gamma);
     } else {                           // shader.py:34-38 / 51-55
-      y = powf((x - lo) / (hi - lo), gamma);
+      y = rm_pow((x - lo) / (hi - lo), gamma);
     }
-    image[3 * i] = y; image[3 * i + 1] = y; image[3 * i + 2] = y;
+    store3_t(image, i, mk3(y, y, y), dt);
   }
 }
 
@@ -806,25 +843,27 @@ __global__ void k_minmax_encode(const float* lohi, uint32_t* mm) {
 }
 
 // standalone PinholeCamera.forward
-__global__ void k_camera_fwd(RmCamera cam, const float* __restrict__ orientation, const float* __restrict__ translation,
-                             float* __restrict__ out_pos, float* __restrict__ out_dirs, float* __restrict__ frames) {
+__global__ void k_camera_fwd(RmCamera cam, const void* __restrict__ orientation, const void* __restrict__ translation,
+                             void* __restrict__ out_pos, void* __restrict__ out_dirs, void* __restrict__ frames) {
+  const int dt = cam.dtype;
   int64_t per_cam = (int64_t)cam.height * cam.width;
   int64_t n = per_cam * cam.num_cameras;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i / per_cam);
-    Pose ps = load_pose(orientation, translation, c);
-    store3(out_pos, i, qrot(load3(cam.ray_positions, i), ps.w, ps.qv) + ps.t);
-    store3(out_dirs, i, qrot(load3(cam.ray_directions, i), ps.w, ps.qv));
+    Pose ps = load_pose(orientation, translation, c, dt);
+    store3_t(out_pos, i, qrot(load3_t(cam.ray_positions, i, dt), ps.w, ps.qv) + ps.t, dt);
+    store3_t(out_dirs, i, qrot(load3_t(cam.ray_directions, i, dt), ps.w, ps.qv), dt);
   }
   // QuaternionToSO3 (quaternion.py:114-124)
   if (frames && blockIdx.x == 0 && (int)threadIdx.x < cam.num_cameras) {
     int c = threadIdx.x;
-    float w = orientation[4 * c], x = orientation[4 * c + 1], y = orientation[4 * c + 2], z = orientation[4 * c + 3];
+    Pose ps = load_pose(orientation, translation, c, dt);
+    float w = ps.w, x = ps.qv.x, y = ps.qv.y, z = ps.qv.z;
     float ww = w * w, wx = w * x, wy = w * y, wz = w * z, xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
-    float* f = frames + 9 * c;
-    f[0] = ((ww + xx) - yy) - zz; f[1] = 2.0f * (xy - wz); f[2] = 2.0f * (wy + xz);
-    f[3] = 2.0f * (xy + wz); f[4] = ((ww - xx) + yy) - zz; f[5] = 2.0f * (yz - wx);
-    f[6] = 2.0f * (xz - wy); f[7] = 2.0f * (wx + yz); f[8] = ((ww - xx) - yy) + zz;
+    const float f[9] = {((ww + xx) - yy) - zz, 2.0f * (xy - wz), 2.0f * (wy + xz),
+                        2.0f * (xy + wz), ((ww - xx) + yy) - zz, 2.0f * (yz - wx),
+                        2.0f * (xz - wy), 2.0f * (wx + yz), ((ww - xx) - yy) + zz};
+    for (int k = 0; k < 9; ++k) st_t(frames, 9 * c + k, f[k], dt);
   }
 }
 
@@ -885,7 +924,7 @@ __global__ void k_camera_bwd(RmCamera cam, const float* __restrict__ orientation
       const float* gsrc = k ? gdirs : gpos;
       if (!gsrc) continue;
       V3 g = load3(gsrc, li);
-      V3 V = load3(k ? cam.ray_directions : cam.ray_positions, gi);
+      V3 V = load3(static_cast<const float*>(k ? cam.ray_directions : cam.ray_positions), gi);
       V3 T = 2.0f * cross(u, V);
       V3 gT = w * g + cross(g, u);
       V3 gu = cross(T, g) + 2.0f * cross(V, gT);
@@ -932,7 +971,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     int64_t li = ((int64_t)cam * rows + row) * W + col;
     int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;
     Pose ps = load_pose(a.orientation, a.translation, cam);
-    V3 v = qrot(load3(a.cam.ray_directions, gi), ps.w, ps.qv);
+    V3 v = qrot(load3(static_cast<const float*>(a.cam.ray_directions), gi), ps.w, ps.qv);
     V3 p = load3(a.p_final, li);
     V3 gi3 = live ? load3(a.grad_image, li) : mk3(0.0f, 0.0f, 0.0f);
     // recompute the normal for the shader VJP
@@ -990,7 +1029,11 @@ __global__ void k_finish_grads(RmScene sc, const float* __restrict__ sums, float
     for (int pc = 0; pc < sc.n_instr; ++pc) {
       int4 w = prog[pc];
       if (w.x != RM_OP_LINE) continue;
-      const float* a = sc.params + w.y;
+      float a[6];
+      for (int k = 0; k < 6; ++k) {
+        if (sc.param_refs) { const RmParamRef r = sc.param_refs[w.y + k]; a[k] = ld_t(r.base, r.elem, r.dtype); }
+        else a[k] = sc.params[w.y + k];
+      }
       float ab[3] = {a[3] - a[0], a[4] - a[1], a[5] - a[2]};
       float len2 = (ab[0] * ab[0] + ab[1] * ab[1]) + ab[2] * ab[2];
       const float* gab = s_acc + w.z;

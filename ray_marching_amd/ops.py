@@ -29,6 +29,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _io(t: torch.Tensor):
+    """Contiguous tensor the kernels can read as is (fp32 or fp16; anything else is converted to fp32)
+    and its RM_DTYPE_* code."""
+    t = t.detach()
+    if t.dtype not in (torch.float32, torch.float16):
+        t = t.float()
+    return t.contiguous(), _abi.dtype_code(t.dtype)
+
+
 def _partials(cs: CompiledScene, params, device):
     s, keep = cs.scene_struct(params, device)
     n = cs.lib(True).rm_grad_partials_floats(s, 0)
@@ -37,6 +46,15 @@ def _partials(cs: CompiledScene, params, device):
 
 def _ck(cs, code, what):
     _abi.check(code, what, cs.lib())
+
+
+def live_params(cs: CompiledScene, device, *inputs):
+    """The packed parameter block (torch.cat: the autograd edge to every nn.Parameter) when a gradient can be
+    asked for, else None: the kernels then gather the parameters from their storages (CompiledScene.param_table)."""
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in cs.leaves) or
+                                    any(t is not None and t.requires_grad for t in inputs)):
+        return cs.pack_params(device)
+    return None
 
 
 def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False) -> int:
@@ -52,22 +70,25 @@ class SDFEval(torch.autograd.Function):
     def forward(ctx, params, points, cs: CompiledScene):
         _require_device(points, "query_positions")
         dev = points.device
-        pts = _f32c(points).reshape(-1, 3)
-        prm = _f32c(params)
+        pts, dt = _io(points)
+        pts = pts.reshape(-1, 3)
+        prm = None if params is None else _f32c(params)
         n = pts.shape[0]
-        out = torch.empty(n, dtype=torch.float32, device=dev)
+        out = torch.empty(n, dtype=pts.dtype, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            _ck(cs, cs.lib().rm_sdf_forward(s, _abi.ptr(pts), _abi.ptr(out), n, _abi.current_stream(dev)),
+            _ck(cs, cs.lib().rm_sdf_forward(s, _abi.ptr(pts), _abi.ptr(out), n, dt, _abi.current_stream(dev)),
                        "rm_sdf_forward")
         ctx.cs = cs
         ctx.in_dtype = points.dtype
-        ctx.save_for_backward(prm, pts)
+        if prm is not None:
+            ctx.save_for_backward(prm, pts)
         return out.view(*points.shape[:-1], 1).to(points.dtype)
 
     @staticmethod
     def backward(ctx, grad_out):
         prm, pts = ctx.saved_tensors
+        pts = pts.float()                      # the backward kernels are fp32 only
         cs, dev = ctx.cs, pts.device
         n = pts.shape[0]
         if n == 0:
@@ -93,25 +114,29 @@ class March(torch.autograd.Function):
         _require_device(pos, "ray_positions")
         _require_device(dirs, "ray_directions")
         dev = pos.device
+        in_dtype = pos.dtype
         shape = torch.broadcast_shapes(pos.shape, dirs.shape)
-        p = _f32c(pos.expand(shape)).reshape(-1, 3)
-        v = _f32c(dirs.expand(shape)).reshape(-1, 3)
-        prm = _f32c(params)
-        n = p.shape[0]
         need_grad = any(ctx.needs_input_grad[:3])
+        if need_grad or pos.dtype != dirs.dtype:
+            pos, dirs = pos.float(), dirs.float()          # training path: fp32 throughout
+        p, dt = _io(pos.expand(shape))
+        v, _ = _io(dirs.expand(shape))
+        p, v = p.reshape(-1, 3), v.reshape(-1, 3)
+        prm = None if params is None else _f32c(params)
+        n = p.shape[0]
         out = torch.empty_like(p)
         traj = torch.empty((steps, n, 3), dtype=torch.float32, device=dev) if (need_grad and steps > 0) else None
         nexec = torch.empty(n, dtype=torch.int32, device=dev) if need_grad else None
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
             _ck(cs, cs.lib().rm_march_forward(s, _abi.ptr(p), _abi.ptr(v), _abi.ptr(out), _abi.ptr(traj),
-                                             _abi.ptr(nexec), n, steps, flags, _abi.current_stream(dev)),
+                                             _abi.ptr(nexec), n, steps, flags, dt, _abi.current_stream(dev)),
                        "rm_march_forward")
-        ctx.cs, ctx.steps, ctx.shape, ctx.in_dtype = cs, steps, shape, pos.dtype
+        ctx.cs, ctx.steps, ctx.shape, ctx.in_dtype = cs, steps, shape, in_dtype
         ctx.pos_shape, ctx.dirs_shape = pos.shape, dirs.shape
         if need_grad:
             ctx.save_for_backward(prm, v, traj, nexec)
-        return out.view(shape).to(pos.dtype)
+        return out.view(shape).to(in_dtype)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -159,22 +184,25 @@ class Normals(torch.autograd.Function):
     def forward(ctx, params, coords, cs: CompiledScene, tetra):
         _require_device(coords, "surface_coords")
         dev = coords.device
-        pts = _f32c(coords).reshape(-1, 3)
-        prm = _f32c(params)
+        pts, dt = _io(coords)
+        pts = pts.reshape(-1, 3)
+        prm = None if params is None else _f32c(params)
         n = pts.shape[0]
         nrm = torch.empty_like(pts)
-        lap = torch.empty(n, dtype=torch.float32, device=dev)
+        lap = torch.empty(n, dtype=pts.dtype, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            _ck(cs, cs.lib().rm_normals_forward(s, tetra, _abi.ptr(pts), _abi.ptr(nrm), _abi.ptr(lap), n,
+            _ck(cs, cs.lib().rm_normals_forward(s, tetra, _abi.ptr(pts), _abi.ptr(nrm), _abi.ptr(lap), n, dt,
                                                _abi.current_stream(dev)), "rm_normals_forward")
         ctx.cs, ctx.tetra, ctx.in_dtype = cs, tetra, coords.dtype
-        ctx.save_for_backward(prm, pts)
+        if prm is not None:
+            ctx.save_for_backward(prm, pts)
         return nrm.view(coords.shape).to(coords.dtype), lap.view(*coords.shape[:-1], 1).to(coords.dtype)
 
     @staticmethod
     def backward(ctx, grad_n, grad_lap):
         prm, pts = ctx.saved_tensors
+        pts = pts.float()
         cs, dev = ctx.cs, pts.device
         n = pts.shape[0]
         gn = _f32c(grad_n).reshape(-1, 3) if grad_n is not None else None
@@ -196,9 +224,12 @@ class Normals(torch.autograd.Function):
 # camera
 # --------------------------------------------------------------------------
 def camera_struct(ray_positions, ray_directions):
+    """RmCamera over the two buffers (same dtype, fp32 or fp16, contiguous)."""
     n, h, w, _ = ray_positions.shape
+    if ray_positions.dtype != ray_directions.dtype:
+        raise ValueError("ray_positions and ray_directions must have one dtype")
     return _abi.RmCamera(ray_positions=ray_positions.data_ptr(), ray_directions=ray_directions.data_ptr(),
-                         num_cameras=n, height=h, width=w)
+                         num_cameras=n, height=h, width=w, dtype=_abi.dtype_code(ray_positions.dtype))
 
 
 def _camera_backward(rp, rd, q, gpos, gdirs, rows, need_q=True, need_t=True):
@@ -224,13 +255,14 @@ class Camera(torch.autograd.Function):
         _require_device(ray_positions, "camera buffers")
         _require_device(orientation, "orientation")
         dev = ray_positions.device
-        rp, rd = _f32c(ray_positions), _f32c(ray_directions)
-        q, t = _f32c(orientation), _f32c(translation)
+        rp, _ = _io(ray_positions)
+        rd = ray_directions.detach().to(rp.dtype).contiguous()
+        q, t = orientation.detach().to(rp.dtype).contiguous(), translation.detach().to(rp.dtype).contiguous()
         n = rp.shape[0]
         if q.shape != (n, 4) or t.shape != (n, 3):
             raise ValueError(f"camera pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
         pos, dirs = torch.empty_like(rp), torch.empty_like(rd)
-        frames = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+        frames = torch.empty((n, 3, 3), dtype=rp.dtype, device=dev)
         with torch.cuda.device(dev):
             cam = camera_struct(rp, rd)
             _abi.check(_lib.rm_camera_forward(cam, _abi.ptr(q), _abi.ptr(t), _abi.ptr(pos), _abi.ptr(dirs),
@@ -243,7 +275,7 @@ class Camera(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gpos, gframes, gdirs):
-        rp, rd, q = ctx.saved_tensors
+        rp, rd, q = (x.float() for x in ctx.saved_tensors)
         gp = _f32c(gpos) if gpos is not None else None
         gd = _f32c(gdirs) if gdirs is not None else None
         if gp is None and gd is None:
@@ -262,6 +294,7 @@ def camera_forward(ray_positions, ray_directions, orientation, translation):
 # fused frame
 # --------------------------------------------------------------------------
 _GLOBAL_MODES = (1, 2, 5)
+_FUSED_VJP_MODES = {0, 4}            # shader modes rm_render_backward differentiates through
 
 
 # measurement hook (bench.py): when set to a list, Render.run appends a (start, end) pair of timing events
@@ -273,54 +306,73 @@ class Render(torch.autograd.Function):
     """RenderLoop.forward as one kernel (+ the normalisation pass of modes 1, 2, 5).
 
     ``allreduce_minmax``: optional callable(lohi_tensor[2]) applied between the two passes
-    (row-tiled multi-GPU rendering all-reduces the global min/max there)."""
+    (row-tiled multi-GPU rendering all-reduces the global min/max there).
+
+    I/O types: the camera buffers' dtype (fp32 or fp16) is the kernel's load type, the pose is passed in the
+    same type, ``image_dtype`` is its store type -- no cast passes.  With anything requiring grad the frame is
+    fp32 (the backward kernels are)."""
 
     @staticmethod
     def forward(ctx, params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions,
                 tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
-                precision: str = "exact"):
+                precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None):
         return Render.run(ctx, ctx.needs_input_grad, params, orientation, translation, cs, ray_positions,
-                          ray_directions, tetra, cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision)
+                          ray_directions, tetra, cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision,
+                          image_dtype, tile_order, tile_cost)
 
     @staticmethod
     def run(ctx, needs_input_grad, params, orientation, translation, cs: CompiledScene, ray_positions,
             ray_directions, tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
-            precision: str = "exact"):
+            precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None):
         """Body of the forward pass.  ``ctx`` is None for inference frames, which skip the autograd
         machinery altogether (render_frame below)."""
         _require_device(ray_positions, "camera buffers")
         _require_device(orientation, "orientations")
         dev = ray_positions.device
-        prm = _f32c(params)
-        q, t = _f32c(orientation), _f32c(translation)
-        n, h, w, _ = ray_positions.shape
+        prm = None if params is None else _f32c(params)       # None: the kernel gathers from the parameter storages
+        need_grad = any(needs_input_grad[:3])
+        have_vjp = mode in _FUSED_VJP_MODES
+        record = need_grad and have_vjp
+        if record and (ray_positions.dtype != torch.float32 or ray_directions.dtype != torch.float32):
+            ray_positions, ray_directions = ray_positions.float(), ray_directions.float()
+        rp, _ = _io(ray_positions)
+        rd = ray_directions.detach().to(rp.dtype).contiguous()
+        q, t = orientation.detach().to(rp.dtype).contiguous(), translation.detach().to(rp.dtype).contiguous()
+        n, h, w, _ = rp.shape
         if q.shape != (n, 4) or t.shape != (n, 3):
             raise ValueError(f"pose shapes {tuple(q.shape)}, {tuple(t.shape)} do not match num_cameras={n}")
         r0, r1 = rows if rows is not None else (0, h)
         nrows = r1 - r0
         R = n * nrows * w
-        need_grad = any(needs_input_grad[:3])
-        if need_grad and mode not in (0, 4):
-            raise NotImplementedError(f"fused backward exists for shader modes 0 (lambertian) and 4 (normal), not {mode}")
-        image = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
-        p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if need_grad else None
-        traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (need_grad and steps > 0) else None
-        nexec = torch.empty(R, dtype=torch.int32, device=dev) if need_grad else None
+        if record:
+            image_dtype = torch.float32
+        elif image_dtype is None:
+            image_dtype = torch.promote_types(rp.dtype, cmap.dtype) if (mode in (6, 7) and cmap is not None) else rp.dtype
+        image = torch.empty((n, nrows, w, 3), dtype=image_dtype, device=dev)
+        first_pass = None
+        if mode in _GLOBAL_MODES:
+            first_pass = image if image_dtype == torch.float32 else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
+        p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if record else None
+        traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
+        nexec = torch.empty(R, dtype=torch.int32, device=dev) if record else None
         minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)   # global min/max words + dynamic tile counter
         with torch.cuda.device(dev):
             stream = _abi.current_stream(dev)
             s, keep = cs.scene_struct(prm, dev)
-            cam = camera_struct(ray_positions, ray_directions)
+            cam = camera_struct(rp, rd)
             _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
             sink = kernel_event_sink
             if sink is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            _abi.check(cs.lib(False, precision).rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
-                                              _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
-                                              _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
-                                              mode, degree, steps, r0, r1, flags, stream), "rm_render_forward",
-                       cs.lib(False, precision))
+            lib = cs.lib(False, precision)
+            _abi.check(lib.rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
+                                             _abi.dtype_code(image_dtype), _abi.ptr(first_pass),
+                                             _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
+                                             _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
+                                             0 if cmap is None else _abi.dtype_code(cmap.dtype),
+                                             mode, degree, steps, r0, r1, flags, _abi.ptr(tile_order), _abi.ptr(tile_cost),
+                                             stream), "rm_render_forward", lib)
             if sink is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
@@ -331,16 +383,23 @@ class Render(torch.autograd.Function):
                     _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
                     allreduce_minmax(lohi)
                     _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
-                _abi.check(_lib.rm_shade_finish(_abi.ptr(image), n * nrows * w, _abi.ptr(minmax), mode, stream),
-                           "rm_shade_finish")
-        if need_grad:
-            ctx.save_for_backward(prm, q, t, ray_positions, ray_directions, p_final, traj, nexec)
-            ctx.cs, ctx.tetra, ctx.mode, ctx.steps, ctx.rows, ctx.flags = cs, tetra, mode, steps, (r0, r1), flags
+                _abi.check(_lib.rm_shade_finish(_abi.ptr(first_pass), _abi.ptr(image), _abi.dtype_code(image_dtype),
+                                                n * nrows * w, _abi.ptr(minmax), mode, stream), "rm_shade_finish")
+        if ctx is not None:
+            ctx.have_vjp = have_vjp
+            ctx.mode = mode
+        if record:
+            ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec)
+            ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
             ctx.precision = precision
         return image
 
     @staticmethod
     def backward(ctx, grad_image):
+        if not ctx.have_vjp:
+            # the frame itself rendered (like the reference, which renders every mode with grad enabled);
+            # only differentiating through a shader without a fused VJP is refused
+            raise NotImplementedError(f"fused backward exists for shader modes {sorted(_FUSED_VJP_MODES)}, not {ctx.mode}")
         prm, q, t, rp, rd, p_final, traj, nexec = ctx.saved_tensors
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
@@ -364,18 +423,21 @@ class Render(torch.autograd.Function):
         if need_pose:
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         gp_out = gprm[: prm.numel()] if ctx.needs_input_grad[0] else None
-        return (gp_out, gq, gt) + (None,) * 12
+        return (gp_out, gq, gt) + (None,) * 15
 
 
 _NO_GRAD = (False, False, False)
 
 
 def render_frame(params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions, tetra, cmap,
-                 mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax, precision: str = "exact"):
+                 mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax, precision: str = "exact",
+                 image_dtype=None, tile_order=None, tile_cost=None):
     """One frame.  Goes through autograd only when something can receive a gradient; an inference frame
     calls the launch code directly (autograd.Function.apply costs ~20 us per call even under no_grad)."""
-    if torch.is_grad_enabled() and (params.requires_grad or orientation.requires_grad or translation.requires_grad):
+    if torch.is_grad_enabled() and ((params is not None and params.requires_grad) or orientation.requires_grad
+                                    or translation.requires_grad):
         return Render.apply(params, orientation, translation, cs, ray_positions, ray_directions, tetra, cmap, mode,
-                            degree, steps, rows, flags, allreduce_minmax, precision)
+                            degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order, tile_cost)
     return Render.run(None, _NO_GRAD, params, orientation, translation, cs, ray_positions, ray_directions, tetra,
-                      cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision)
+                      cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order,
+                      tile_cost)

@@ -67,7 +67,7 @@ class SDFMarcher(nn.Module):
 
     def forward(self, ray_positions: Tensor, ray_directions: Tensor, marching_steps: int = 32) -> Tensor:
         cs = compiled_for(self.sdf_scene)
-        return ops.March.apply(cs.pack_params(ray_positions.device), ray_positions, ray_directions, cs,
+        return ops.March.apply(ops.live_params(cs, ray_positions.device, ray_positions, ray_directions), ray_positions, ray_directions, cs,
                                int(marching_steps), ops.default_flags(self.early_out))
 
 
@@ -103,4 +103,4 @@ class SDFNormals(nn.Module):
 
     def forward(self, surface_coords: Tensor):
         cs = compiled_for(self.sdf_scene)
-        return ops.Normals.apply(cs.pack_params(surface_coords.device), surface_coords, cs, self.tetra())
+        return ops.Normals.apply(ops.live_params(cs, surface_coords.device, surface_coords), surface_coords, cs, self.tetra())

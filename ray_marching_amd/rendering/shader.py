@@ -66,11 +66,18 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
     q = None if orientation is None else _f32c(orientation).reshape(-1, 4)
     fr = None if frames is None else _f32c(frames).reshape(-1, 9)
     cm = None
+    out_dtype = in_dtype if in_dtype in (torch.float32, torch.float16) else torch.float32
     if mode in (6, 7):
         if cmap is None:
             raise ValueError("tangent / spin shaders need a colormap")
-        cm = _f32c(cmap).to(dev)
-    image = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        cm = cmap.detach()
+        if cm.dtype not in (torch.float64, torch.float32, torch.float16):
+            cm = cm.float()
+        cm = cm.to(dev).contiguous()
+        # brightness (input dtype) * colormap row: torch type promotion, e.g. fp32 * float64 -> float64 (shader.py:118)
+        out_dtype = torch.promote_types(out_dtype, cm.dtype)
+    first_dtype = torch.float32 if mode in _GLOBAL else out_dtype
+    image = torch.empty((n, 3), dtype=first_dtype, device=dev)
     minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev) if mode in _GLOBAL else None
     with torch.cuda.device(dev):
         stream = _abi.current_stream(dev)
@@ -78,8 +85,9 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
             _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
         _abi.check(_lib.rm_shade_forward(_abi.ptr(bufs["px"]), _abi.ptr(q), _abi.ptr(fr), _abi.ptr(bufs["dirs"]),
                                          _abi.ptr(bufs["coords"]), _abi.ptr(bufs["normals"]), _abi.ptr(bufs["lap"]),
-                                         _abi.ptr(bufs["dist"]), _abi.ptr(image), _abi.ptr(minmax), _abi.ptr(cm),
-                                         0 if cm is None else cm.shape[0], mode, degree, n, per_cam, stream),
+                                         _abi.ptr(bufs["dist"]), _abi.ptr(image), _abi.dtype_code(first_dtype),
+                                         _abi.ptr(minmax), _abi.ptr(cm), 0 if cm is None else cm.shape[0],
+                                         0 if cm is None else _abi.dtype_code(cm.dtype), mode, degree, n, per_cam, stream),
                    "rm_shade_forward")
         if minmax is not None:
             if allreduce_minmax is not None:
@@ -87,12 +95,13 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
                 _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
                 allreduce_minmax(lohi)
                 _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
-            _abi.check(_lib.rm_shade_finish(_abi.ptr(image), n, _abi.ptr(minmax), mode, stream), "rm_shade_finish")
+            final = image if out_dtype == torch.float32 else torch.empty((n, 3), dtype=out_dtype, device=dev)
+            _abi.check(_lib.rm_shade_finish(_abi.ptr(image), _abi.ptr(final), _abi.dtype_code(out_dtype), n,
+                                            _abi.ptr(minmax), mode, stream), "rm_shade_finish")
+            image = final
     ch = 3 if mode in _THREE_CHANNEL else 1
     out = image.view(*lead, 3)[..., :ch]
-    if mode in (6, 7) and cmap is not None and cmap.dtype == torch.float64:
-        return out.double()  # the reference's brightness * float64 colormap promotes to float64
-    return out.to(in_dtype)
+    return out if mode in (6, 7) else out.to(in_dtype)
 
 
 def _no_grad_inputs(*tensors):

@@ -5,7 +5,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ..compiler import compiled_for
-from ..ops import SDFEval
+from ..ops import SDFEval, live_params
 
 
 class SDFNode(nn.Module):
@@ -20,4 +20,4 @@ class SDFNode(nn.Module):
         if query_positions.shape[-1] != 3:
             raise ValueError(f"query_positions must be [..., 3], got {tuple(query_positions.shape)}")
         cs = compiled_for(self)
-        return SDFEval.apply(cs.pack_params(query_positions.device), query_positions, cs)
+        return SDFEval.apply(live_params(cs, query_positions.device, query_positions), query_positions, cs)

@@ -72,6 +72,14 @@ def report(name, got, want):
     return float(err.max()) if err.numel() else 0.0, float((err > 1e-5).double().mean()) if err.numel() else 0.0
 
 
+def ulp_distance(got, want):
+    """|got - want| in fp32 units in the last place (bit patterns as ordered integers), int64 tensor."""
+    def ordered(t):
+        b = torch.as_tensor(t).detach().float().cpu().contiguous().view(torch.int32).long()
+        return torch.where(b < 0, -(b & 0x7fffffff), b)
+    return (ordered(got) - ordered(want)).abs()
+
+
 def random_spec(gen, depth=0, max_depth=4):
     """Random SDF tree over all 11 node types (oracle spec); `gen` is a torch.Generator."""
     def u(lo, hi, n=None):

@@ -1,0 +1,194 @@
+"""BASELINE configs 3 and 5 at their own size and iteration count, and the native fp16 I/O path.
+
+configs[2]: make_test_scene2, 3840x2160, 256 march steps, module .to(float16)  (main.py:20-26 runs float16)
+configs[4]: 32-primitive smooth-union scene in a room, 7680x4320, 256 steps, 8 row bands of 540 rows
+
+The oracle cannot render these frames in the time a test has, so the full frames are checked through
+size-independent properties (early-out on/off, row-band reassembly, interpreter == specialised kernels, finite
+values) and a strided pixel sample is compared with the oracle at the full step count, bit for bit.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import sdf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _fp16_oracle_inputs(spec, n, w, h):
+    """What a reference module cast with .to(float16) holds, as fp32 tensors: fp16-rounded parameters, camera
+    buffers and tetrahedron constants (the kernels read fp16 storage and compute in fp32)."""
+    r = lambda x: x.half().float()
+    bufs = tuple(r(b) for b in O.camera_buffers(n, w, h, H.PX * h, H.PX * w, H.PX * h))
+    tetra = tuple(r(c) for c in O.tetra_constants(H.EPS))
+    return O.map_spec(spec, r), bufs, tetra
+
+
+@pytest.mark.parametrize("shape", [(1, 90, 160), (2, 33, 47)])
+def test_fp16_io_equals_fp32_arithmetic_on_fp16_storage(shape):
+    """RenderLoop.to(float16): fp16 camera buffers, parameters, pose and image, fp32 arithmetic in between.
+    That is exactly the fp32 oracle evaluated on the fp16-rounded inputs with its result rounded once to fp16 --
+    compared bit for bit, every shader mode (the reference's own fp16 path rounds after EVERY ATen op and sits
+    up to 0.66 away from its fp32 path, see test_fp16_io_config3_numerics for that statistical comparison)."""
+    n, h, w = shape
+    steps = 48
+    spec = O.scene_test2()
+    loop = H.make_loop(H.spec_to_module(spec), h, w, n=n).to(torch.float16)
+    assert loop.camera.ray_positions.dtype == torch.float16 and loop.scene.sdfs[0].radius.dtype == torch.float16
+    cmap16 = loop.shader.cyclic_cmap                     # .to(float16) cast the registered buffer like the reference's
+    assert cmap16.dtype == torch.float16
+    spec16, bufs, tetra = _fp16_oracle_inputs(spec, n, w, h)
+    gen = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0, 0.0]]) + 0.1 * torch.randn(n, 4, generator=gen), dim=-1).half()
+    t = (torch.tensor([[0.0, 0.0, -3.0]]) + 0.2 * torch.randn(n, 3, generator=gen)).half()
+    for mode in range(8):
+        with torch.no_grad(), O.math_mode("restated"):
+            want = O.render(spec16, bufs, q.float(), t.float(), mode, 2, steps, H.EPS, cmap=cmap16.float().cpu(),
+                            tetra=tetra).half()
+            got = loop(q.to(DEV), t.to(DEV), mode, 2, steps)
+        assert got.dtype == torch.float16 and got.shape == (n, h, w, 3)
+        assert H.report(f"fp16 mode {mode}", got, want)[0] == 0.0, mode
+
+
+def test_fp16_frame_is_one_kernel_and_no_cast_passes():
+    """The fp16 frame issues the workspace init and ONE frame kernel -- no torch cast / copy kernels (the
+    round-1 plumbing converted buffers, pose and image in separate passes)."""
+    from torch.profiler import ProfilerActivity, profile
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), 120, 160).to(torch.float16)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV).half()
+    t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV).half()
+    with torch.no_grad():
+        for _ in range(3):
+            loop(q, t, 4, 1, 32)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            img = loop(q, t, 4, 1, 32)
+            torch.cuda.synchronize()
+    assert img.dtype == torch.float16
+    kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    if not kernels:
+        pytest.skip("the profiler recorded no device activity on this box")
+    print("kernels of one fp16 frame:", kernels)
+    assert sum("k_render_fwd" in k for k in kernels) == 1
+    others = [k for k in kernels if "k_render_fwd" not in k and "k_minmax_init" not in k and "Memset" not in k]
+    assert not others, others
+
+
+def test_config3_full_size_fp16(monkeypatch):
+    """configs[2] at 3840x2160, 256 steps, float16 module."""
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compiled_for
+    h, w, steps = 2160, 3840, 256
+    spec = O.scene_test2()
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV).half()
+    t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV).half()
+    frames = {}
+    for path in ("auto", "off"):
+        monkeypatch.setenv("RM_SPECIALIZE", path)
+        specialize._loaded.clear()
+        loop = H.make_loop(H.spec_to_module(spec), h, w).to(torch.float16)
+        assert compiled_for(loop.scene).specialised == (path == "auto")
+        with torch.no_grad():
+            frames[path] = {m: loop(q, t, m, 1, steps) for m in (4, 0)}
+        if path == "auto":
+            loop_full = H.make_loop(H.spec_to_module(spec), h, w, early_out=False).to(torch.float16)
+            with torch.no_grad():
+                for m in (4, 0):
+                    a = frames[path][m]
+                    assert a.dtype == torch.float16 and a.shape == (1, h, w, 3) and torch.isfinite(a).all()
+                    assert torch.equal(a, loop_full(q, t, m, 1, steps)), "early-out changed pixels"
+                    bands = [loop(q, t, m, 1, steps, rows=(r, r + h // 8)) for r in range(0, h, h // 8)]
+                    assert torch.equal(torch.cat(bands, dim=1), a), "8 row bands do not reassemble to the frame"
+    specialize._loaded.clear()
+    for m in (4, 0):
+        assert torch.equal(frames["auto"][m], frames["off"][m]), "specialised kernels != interpreter"
+    # every 32nd pixel of the frame vs the oracle at the full 256 steps (fp32 arithmetic on the fp16 storage)
+    stride = 32
+    spec16, bufs, tetra = _fp16_oracle_inputs(spec, 1, w, h)
+    sub = tuple(b[:, ::stride, ::stride].contiguous() for b in bufs)
+    for m in (4, 0):
+        with torch.no_grad():
+            want = O.render(spec16, sub, q.float().cpu(), t.float().cpu(), m, 1, steps, H.EPS, tetra=tetra).half()
+        assert H.report(f"config 3 mode {m}", frames["auto"][m][:, ::stride, ::stride], want)[0] == 0.0
+
+
+def test_config5_full_size_band_and_frame(monkeypatch):
+    """configs[4]: the 7680x4320 frame of the 32-primitive scene at 256 steps, as 8 bands of 540 rows."""
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
+    h, w, steps, bands = 4320, 7680, 256, 8
+    rows = h // bands
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -4.5]], device=DEV)
+    band = (3 * rows, 4 * rows)                           # rows 1620 .. 2160: through the middle of the objects
+    out = {}
+    for path in ("auto", "off"):
+        monkeypatch.setenv("RM_SPECIALIZE", path)
+        specialize._loaded.clear()
+        loop = H.make_loop(make_many_primitive_scene(32), h, w)
+        assert compiled_for(loop.scene).specialised == (path == "auto")
+        with torch.no_grad():
+            out[path] = loop(q, t, 4, 1, steps, rows=band)
+        if path == "auto":
+            a = out[path]
+            assert a.shape == (1, rows, w, 3) and torch.isfinite(a).all()
+            loop_full = H.make_loop(make_many_primitive_scene(32), h, w, early_out=False)
+            with torch.no_grad():
+                assert torch.equal(a, loop_full(q, t, 4, 1, steps, rows=band)), "early-out changed pixels"
+                # the whole 8K frame in one launch == the 8 bands a node renders, reassembled
+                whole = loop(q, t, 4, 1, steps)
+                assert torch.equal(whole[:, band[0]:band[1]], a)
+                for b in (0, 7):
+                    assert torch.equal(loop(q, t, 4, 1, steps, rows=(b * rows, (b + 1) * rows)), whole[:, b * rows:(b + 1) * rows])
+                # a globally normalised shader over bands: min/max folded across launches through the hook
+                del whole
+    specialize._loaded.clear()
+    assert torch.equal(out["auto"], out["off"]), "specialised kernels != interpreter"
+    # every 32nd pixel of the band vs the oracle at 256 steps (host-independent exp/log), bit for bit
+    stride = 32
+    bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    sub = tuple(b[:, band[0]:band[1]:stride, ::stride].contiguous() for b in bufs)
+    with torch.no_grad(), O.math_mode("restated"):
+        want = O.render(O.scene_many(32), sub, q.cpu(), t.cpu(), 4, 1, steps, H.EPS)
+    assert H.report("config 5 band", out["auto"][:, ::stride, ::stride], want)[0] == 0.0
+
+
+def test_main_py_loop_through_pose_player_and_frame_sink(tmp_path):
+    """The reference's frame loop (main.py:53-88) on a display-less node: PosePlayer stands in for
+    EventAggregator.get_state(), RenderLoop renders, FrameSink stands in for Window.draw and receives
+    F.pad(images.mean(0).float(), [0,1], value=1.0) -- contiguous [H,W,4] fp32 (torchwindow/window.py:146-174)."""
+    import torch.nn.functional as F
+    from ray_marching_amd.headless import FrameSink, PosePlayer, to_rgba
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    n, h, w = 2, 45, 80
+    loop = H.make_loop(make_test_scene2(), h, w, n=n)
+    # the reference's start pose (main.py:46-49) for camera 0, a second camera outside the torus; flying backwards
+    # while yawing, shader mode advanced every frame (the scroll wheel): all 8 modes in 8 frames
+    events = PosePlayer(initial_position=[[0.0, 0.0, 1.0], [0.3, -0.2, -3.0]],
+                        initial_orientation=[[1.0, 0.0, 0.0, 0.0], [0.9, 0.1, -0.3, 0.2]], marching_steps=32, mode=0,
+                        degree=2, velocity=(0.0, 0.0, -1.5), angular_velocity=(0.0, 0.2, 0.0), mode_every=1, device=DEV)
+    window = FrameSink(width=w, height=h, out_dir=str(tmp_path))
+    bufs = O.camera_buffers(n, w, h, H.PX * h, H.PX * w, H.PX * h)
+    cmap = loop.shader.cyclic_cmap.cpu()
+    seen = set()
+    with torch.no_grad():
+        for i in range(8):
+            positions, orientations, mode, degree, marching_steps, _ = events.get_state()      # main.py:56-63
+            images = loop(orientations, positions, mode, degree, marching_steps)                  # main.py:65-71
+            window.draw(F.pad(images.mean(0).float(), [0, 1], value=1.0))                         # main.py:78-84
+            seen.add(mode % 8)
+            with O.math_mode("restated"):
+                want = O.render(O.scene_test2(), bufs, orientations.cpu(), positions.cpu(), mode, degree,
+                                marching_steps, H.EPS, cmap=cmap)
+            want = F.pad(want.mean(0).float(), [0, 1], value=1.0)
+            got = window.latest()
+            assert got.shape == (h, w, 4) and got.dtype == torch.float32 and got.is_contiguous()
+            assert torch.equal(got, to_rgba(images).cpu())
+            assert H.report(f"sink frame {i} (mode {mode % 8})", got, want)[0] == 0.0
+    window.close()
+    assert window.frames == 8 and seen == set(range(8))
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".ppm")) == [f"frame_{i:05d}.ppm" for i in range(8)]

@@ -1,8 +1,10 @@
 """HIP kernels (through the C ABI) vs the committed reference outputs and vs the oracle.
 
-Tolerance (north_star): forward pixels within 1e-5 fp32.  The kernels follow the
-reference's ATen op order with FMA contraction off, so most outputs are in fact bit-exact;
-the asserts below use 1e-5 (and say where a tighter bound holds).
+Tolerance (north_star): forward pixels within 1e-5 fp32.  The kernels follow the reference's ATen op order
+with FMA contraction off; pow and atan2 restate the Sleef functions ATen calls (tests/test_math_sweep.py), so
+everything without a smooth union is asserted BIT-EXACT, all eight shader modes included.  torch.logsumexp
+goes through MKL VML exp/log, whose bits depend on the host CPU (profiles/host_math_probe.py): there the
+device computes the correctly rounded value, and the asserts are "within 1 ulp per node" / 1e-5 per pixel.
 """
 import os
 
@@ -57,10 +59,13 @@ def test_nodes_vs_golden(name):
         got = module(pts)
     assert got.shape == (pts.shape[0], 1)
     mx, frac = H.report(name, got, g[name])
-    print(f"{name}: max|err|={mx:.3g}")
-    assert mx <= 2e-6, (name, mx)
-    if name not in ("smooth_union", "scene1", "scene1_closed", "scene_many8"):
-        assert mx == 0.0, f"{name} expected bit-exact, got {mx}"   # no transcendental in these nodes
+    ulps = H.ulp_distance(got, g[name])
+    print(f"{name}: max|err|={mx:.3g}, {int((ulps > 0).sum())} of {ulps.numel()} values differ, worst {int(ulps.max())} ulp")
+    if name in ("smooth_union", "scene1", "scene1_closed", "scene_many8"):
+        # logsumexp: MKL's exp/log (fixture host) vs the correctly rounded ones, <= 1 ulp each, 1.5 % / 0.01 % of inputs
+        assert int(ulps.max()) <= 1 and float((ulps > 0).double().mean()) <= 0.01, (name, int(ulps.max()))
+    else:
+        assert mx == 0.0, f"{name} expected bit-exact, got {mx}"
 
 
 def test_leading_shapes_and_empty():
@@ -144,34 +149,28 @@ def test_frames_vs_golden(name, early, kernel_path):
         mx, frac = H.report(f"{name} mode{m}", got, want)
         print(f"{name} mode {m} early={early}: max|err|={mx:.3g} frac>1e-5={frac:.3g}")
         if m in (6, 7):
-            # colormap index = floor(angle * 4096 * degree): an ulp of atan2f can move a pixel to the
-            # neighbouring colormap entry (|delta colour| ~ 2e-3).  Allow <1% such pixels.
-            assert frac <= 0.01 and mx <= 5e-3, (m, mx, frac)
-            assert img.dtype == torch.float64
-        elif m in (1, 2, 5):
-            # globally normalised shaders end in x^(1/2.33), whose slope is unbounded at x = 0:
-            # a 1-ulp difference between ocml logf and ATen's Sleef logf on the pixels next to the
-            # global minimum is amplified to ~3e-4.  The 1e-5 bound holds before the gamma.
-            lin_g = torch.nan_to_num(got.double().cpu()).pow(2.33)      # NaN positions already
-            lin_w = torch.nan_to_num(torch.from_numpy(want).double()).pow(2.33)  # checked by report()
-            assert (lin_g - lin_w).abs().max().item() <= TOL, (name, m)
-            assert mx <= 1e-3 and frac <= 0.02, (name, m, mx, frac)
-        else:
-            assert mx <= TOL, (name, m, mx)
-            if exact_scene and m in (0, 3, 4):
-                assert mx == 0.0, f"mode {m} on scene2 expected bit-exact, got {mx}"
+            assert img.dtype == torch.float64      # fp32 brightness * float64 colormap (shader.py:104,118)
+        assert mx <= TOL, (name, m, mx)
+        if exact_scene:
+            # every mode, the image itself: atan2 / pow are Sleef's bits, the distance shaders' log lands on
+            # MKL's value for these pixels, the colormap product is taken in float64
+            assert mx == 0.0, f"mode {m} on scene2 expected bit-exact, got {mx}"
     # intermediate tensors through the stand-alone modules (marcher / normals / scene call)
     with torch.no_grad():
         pos, frames, _, dirs = loop.camera(q, t)
         p = loop.marcher(pos, dirs, steps)
         n, lap = loop.normals(p)
         dist = loop.scene(p)
-    tight = 0.0 if exact_scene else TOL   # smooth-union scenes: expf/logf differ from Sleef by ulps
-    assert H.report("p", p, g["p"])[0] <= tight
-    assert H.report("n", n, g["n"])[0] <= (0.0 if exact_scene else TOL)
+    tight = 0.0 if exact_scene else 1e-6   # smooth-union scene: exp/log are MKL's on the fixture host (<= 1 ulp away)
+    errs = {"p": H.report("p", p, g["p"])[0], "n": H.report("n", n, g["n"])[0]}
     if "dist" in g.files:
-        assert H.report("dist", dist, g["dist"])[0] <= tight
-        assert H.report("lap", lap, g["lap"])[0] <= (0.0 if exact_scene else 2e-3)
+        errs["dist"] = H.report("dist", dist, g["dist"])[0]
+        errs["lap"] = H.report("lap", lap, g["lap"])[0]
+    print(f"{name} intermediates: " + " ".join(f"{k}={v:.3g}" for k, v in errs.items()))
+    assert errs["p"] <= tight and errs["n"] <= (0.0 if exact_scene else TOL)
+    if "dist" in errs:
+        # Laplacian = (centre - mean of 4 taps) * 6/eps^2 = 2400 x a difference of distances: 1 ulp of one tap is 1.4e-4
+        assert errs["dist"] <= tight and errs["lap"] <= (0.0 if exact_scene else 5e-4)
 
 
 @pytest.mark.parametrize("loss_name,mode", [("lambert_mse", 0), ("normal_sq", 4)])
@@ -354,21 +353,43 @@ def test_static_and_generic_agree_bitwise(monkeypatch):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
 
 
-def test_config5_scene_vs_oracle():
-    """32-primitive smooth-union scene (config 5 shape, small frame) against the oracle."""
+def test_config5_scene_vs_golden_and_host_spread():
+    """32-primitive smooth-union scene (config 5 shape, small frame) against the reference's output from the
+    build container (fixture f9) -- and, next to it, how far the SAME reference arithmetic lands from that
+    fixture when it runs on this box's CPU (oracle = the reference's ATen op stream; its logsumexp is MKL VML,
+    which is CPU-dispatched).  A few rays graze a blend crease where one ulp of exp() decides which object
+    they end on, so 1e-5 cannot hold for every pixel of ANY two evaluations that are not the same binary on the
+    same CPU; the device (correctly rounded exp/log, host independent) has to be no further from the
+    fixture than the reference is from itself."""
     from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
-    h, w, steps = 54, 96, 128
+    g = H.gold("f9_many32_54x96_s128.npz")
+    h, w = (int(x) for x in g["hw"]); steps = int(g["steps"])
     loop = H.make_loop(make_many_primitive_scene(32), h, w)
-    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -4.5]])
+    q, t = torch.from_numpy(g["q"]), torch.from_numpy(g["t"])
     bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
     spec = O.scene_many(32)
+    with torch.no_grad():
+        pos, frames, _, dirs = loop.camera(q.to(DEV), t.to(DEV))
+        p_err = H.report("p", loop.marcher(pos, dirs, steps), g["p"])
+    print(f"config5 scene p_final vs fixture: max|err|={p_err[0]:.3g} frac>1e-5={p_err[1]:.3g}")
     for mode in (0, 4):
         with torch.no_grad():
-            want = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
+            host = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
+            with O.math_mode("restated"):      # same op stream, exp/log of oracle/rm_math_ref.c: host independent
+                exact = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
             got = loop(q.to(DEV), t.to(DEV), mode, 1, steps)
-        mx, frac = H.report(f"config5 mode {mode}", got, want)
-        print(f"config5 scene mode {mode}: max|err|={mx:.3g} frac>1e-5={frac:.3g}")
-        assert frac <= 0.002 and mx <= 1e-3, (mode, mx, frac)   # see DESIGN.md: expf/logf ulps at grazing hits
+        # everything but MKL's ulps is pinned bit for bit, at every pixel: 128 steps x 32 affine primitives,
+        # ATen's summation order inside logsumexp, the culling, the early-out
+        assert H.report(f"config5 mode {mode} restated", got, exact)[0] == 0.0
+        want = g[f"mode{mode}"]
+        ch = want.shape[-1]
+        mx, frac = H.report(f"config5 mode {mode}", got[..., :ch], want)
+        hmx, hfrac = H.report(f"config5 mode {mode} host", host[..., :ch], want)
+        print(f"config5 scene mode {mode}: device vs fixture max|err|={mx:.3g} frac>1e-5={frac:.3g}; "
+              f"this host's reference arithmetic vs fixture max|err|={hmx:.3g} frac>1e-5={hfrac:.3g}")
+        assert frac <= 1e-3 and mx <= 1e-3, (mode, mx, frac)
+        if hfrac > 0:          # a host whose MKL path differs from the fixture's: the yardstick
+            assert frac <= 2.0 * hfrac + 2e-4, (mode, frac, hfrac)
 
 
 def test_two_camera_batch_vs_golden(kernel_path):
@@ -384,7 +405,7 @@ def test_two_camera_batch_vs_golden(kernel_path):
         assert img.shape == (2, h, w, 3)
         want = g[f"mode{m}"]
         mx, _ = H.report(f"two cameras mode {m}", img[..., : want.shape[-1]], want)
-        assert mx <= (TOL if m == 1 else 0.0), (m, mx)
+        assert mx == 0.0, (m, mx)
     with pytest.raises(ValueError):
         loop(q[:1], t[:1], 0, 1, 8)       # pose batch must match num_cameras
 
@@ -519,11 +540,13 @@ def test_ragged_frames_vs_oracle(shape, tile8, kernel_path):
                 assert torch.equal(band, got[:, 1:h - 1])
     # one globally normalised mode: min/max over ALL cameras (shader.py:35-36)
     if n * h * w > 1:
-        with torch.no_grad():
+        with torch.no_grad(), O.math_mode("restated"):
+            # the oracle's log from oracle/rm_math_ref.c (correctly rounded): this box's MKL log sits 1 ulp away
+            # on ~1e-5 of inputs, which x^(1/2.33) would amplify next to the global minimum.  The fixtures from the
+            # build container (test_frames_vs_golden) pin the same shader to the reference's own bits.
             want = O.render(spec, bufs, q, t, 1, 1, 24, H.EPS)
             got = loop(q.to(DEV), t.to(DEV), 1, 1, 24)
-        mx, frac = H.report(f"{shape} distance", got, want)
-        assert mx <= 1e-3 and torch.nan_to_num(got.cpu().double()).pow(2.33).sub(torch.nan_to_num(want.double()).pow(2.33)).abs().max() <= TOL
+        assert H.report(f"{shape} distance", got, want)[0] == 0.0
 
 
 def test_bad_calls_raise():
@@ -643,7 +666,10 @@ def test_random_scene_trees_vs_oracle(seed):
     (d_gpu * wts.to(DEV)).sum().backward()
     exact = not H.spec_has(spec, "smooth_union")
     mx, _ = H.report(f"tree {seed}", d_gpu, d_cpu)
-    assert mx <= (0.0 if exact else 2e-5), (seed, mx)
+    assert mx <= (0.0 if exact else 2e-6), (seed, mx)       # aten mode: this host's MKL exp/log in the smooth unions
+    spec_ng = O.map_spec(spec, lambda x: x.detach())
+    with torch.no_grad(), O.math_mode("restated"):            # host-independent exp/log: bit-exact for every tree
+        assert H.report(f"tree {seed} restated", d_gpu, O.sdf_eval(spec_ng, pts))[0] == 0.0
     gscale = max(1.0, p_cpu.grad.abs().max().item())
     assert H.report("grad points", p_gpu.grad, p_cpu.grad)[0] <= 2e-5 * gscale
     for (pname, want), (_, got) in zip(O.spec_parameters(spec), module.named_parameters()):
@@ -657,16 +683,14 @@ def test_random_scene_trees_vs_oracle(seed):
     from ray_marching_amd.rendering.ray_marching import SDFMarcher, SDFNormals
     o = torch.tensor([[0.0, 0.0, -4.0]]).expand(256, 3).contiguous()
     v = torch.nn.functional.normalize(torch.rand(256, 3, generator=gen) - torch.tensor([0.5, 0.5, -0.5]), dim=-1)
-    with torch.no_grad():
-        spec_ng = O.map_spec(spec, lambda x: x.detach())
+    with torch.no_grad(), O.math_mode("restated"):
         p_ref = O.march(spec_ng, o, v, 12)
         n_ref, lap_ref = O.normals(spec_ng, p_ref, H.EPS)
         p_got = SDFMarcher(module)(o.to(DEV), v.to(DEV), 12)
         n_got, lap_got = SDFNormals(module, H.EPS).to(DEV)(p_got)
-    tol = 0.0 if exact else 1e-4
-    assert H.report("march", p_got, p_ref)[0] <= tol * max(1.0, float(torch.nan_to_num(p_ref, posinf=0, neginf=0).abs().max()))
-    if exact:
-        assert H.report("normals", n_got, n_ref)[0] == 0.0
+    assert H.report("march", p_got, p_ref)[0] == 0.0
+    assert H.report("normals", n_got, n_ref)[0] == 0.0
+    assert H.report("laplacian", lap_got, lap_ref)[0] == 0.0
 
 
 @pytest.mark.parametrize("case", ["scene2", "scene1c", "many32"] + [f"tree{i}" for i in (4, 11, 13, 14, 17, 18, 21)])
@@ -967,7 +991,7 @@ def test_module_surface_edge_cases():
     with torch.no_grad():
         d16 = module.half()(x16)
         want = O.sdf_eval(O.map_spec(spec, lambda t: t.half().float()), x16.float().cpu())
-    assert d16.dtype == torch.float16 and (d16.float().cpu() - want).abs().max().item() <= 2e-3
+    assert d16.dtype == torch.float16 and torch.equal(d16.cpu(), want.half())   # fp16 storage, fp32 arithmetic, one rounding
     # 3. a scene without parameters
     plane = SDFPlane().to(DEV)
     x = torch.randn(100, 3, generator=gen).to(DEV).requires_grad_(True)

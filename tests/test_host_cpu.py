@@ -39,22 +39,39 @@ def test_library_exports_every_declared_symbol():
 def test_bad_arguments_return_error_codes_without_launching():
     from ray_marching_amd import _abi
     lib = _abi.lib
-    assert lib.rm_sdf_forward(None, None, None, 4, None) == -1
+    assert lib.rm_sdf_forward(None, None, None, 4, 0, None) == -1
     assert b"scene" in lib.rm_last_error()
     bogus = _abi.RmScene(program=1, params=1, n_instr=0, n_params=0, n_derived=0, stack_floats=0, n_slots=0)
-    assert lib.rm_sdf_forward(bogus, None, None, 4, None) == -1
+    assert lib.rm_sdf_forward(bogus, None, None, 4, 0, None) == -1
     ok = _abi.RmScene(program=16, params=16, n_instr=1, n_params=1, n_derived=0, stack_floats=0, n_slots=0)
-    assert lib.rm_sdf_forward(ok, None, None, 4, None) == -1          # null buffers
-    assert lib.rm_sdf_forward(ok, None, None, 0, None) == 0           # empty input: nothing to do
-    assert lib.rm_shade_finish(None, 10, None, 1, None) == -1
+    assert lib.rm_sdf_forward(ok, None, None, 4, 0, None) == -1          # null buffers
+    assert lib.rm_sdf_forward(ok, 16, 16, 4, 2, None) == -1              # fp64 points: not an I/O type
+    assert b"dtype" in lib.rm_last_error()
+    assert lib.rm_sdf_forward(ok, None, None, 0, 0, None) == 0           # empty input: nothing to do
+    refs_only = _abi.RmScene(program=16, params=None, param_refs=16, n_instr=1, n_params=1, n_derived=0, stack_floats=0, n_slots=0)
+    assert lib.rm_sdf_forward(refs_only, None, None, 0, 1, None) == 0    # a gather table instead of the packed block
+    neither = _abi.RmScene(program=16, params=None, param_refs=None, n_instr=1, n_params=1, n_derived=0, stack_floats=0, n_slots=0)
+    assert lib.rm_sdf_forward(neither, None, None, 0, 0, None) == -1
+    assert lib.rm_shade_finish(None, None, 0, 10, None, 1, None) == -1
+    assert lib.rm_shade_finish(16, 16, 1, 10, 16, 1, None) == -1         # fp16 image cannot be normalised in place
     assert lib.rm_minmax_init(None, None) == -1
-    cam = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4)
+    cam = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4, dtype=0)
     tet = _abi.RmTetra()
-    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 9, 1, 8, 0, 4, 0, None) == -1
-    assert b"mode" in lib.rm_last_error()
-    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 0, 1, 8, 2, 9, 0, None) == -1
-    assert lib.rm_render_forward(ok, cam, tet, 16, 16, 16, None, None, None, None, None, 0, 1, 1, 8, 0, 4, 0, None) == -1
-    assert b"minmax" in lib.rm_last_error()
+
+    def render(mode, r0=0, r1=4, image_dtype=0, cam_=cam, cmap=None, cmap_dtype=0):
+        return lib.rm_render_forward(ok, cam_, tet, 16, 16, 16, image_dtype, None, None, None, None, None, cmap,
+                                     0 if cmap is None else 8, cmap_dtype, mode, 1, 8, r0, r1, 0, None, None, None)
+
+    assert render(9) == -1 and b"mode" in lib.rm_last_error()
+    assert render(0, 2, 9) == -1                                          # band outside the frame
+    assert render(1) == -1 and b"minmax" in lib.rm_last_error()
+    assert render(0, image_dtype=2) == -1 and b"F64" in lib.rm_last_error()   # float64 image only for modes 6, 7
+    assert render(6) == -1 and b"colormap" in lib.rm_last_error()
+    assert render(6, cmap=16, cmap_dtype=7) == -1
+    cam64 = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4, dtype=2)
+    assert render(0, cam_=cam64) == -1 and b"camera dtype" in lib.rm_last_error()
+    assert lib.rm_wave_tiles(1, 1080, 1920, _abi.FLAG_TILE8X8) == 135 * 240
+    assert lib.rm_wave_tiles(2, 9, 65, 0) == (2 * 9 * 65 + 63) // 64
 
 
 def _validate(rows, n_params, n_derived, stack, slots):
@@ -107,11 +124,61 @@ def test_compiler_lowers_reference_scenes():
     flat = cs.pack_params("cpu")
     assert flat.requires_grad and flat.shape == (14,)
     assert torch.equal(flat[cs.leaf_offsets[5]:cs.leaf_offsets[5] + 3].detach(), scene.sdfs[1].sdfs[2].start.detach())
+    # ... and always reflects the live values: in-place edits, optimiser steps, and writes through .data (which
+    # do not bump the version counter) -- there is no cache to go stale
     with torch.no_grad():
-        a = cs.pack_params("cpu")
-        assert a is cs.pack_params("cpu")                      # cached while parameters are unchanged
         scene.sdfs[0].radius.add_(0.5)
         assert cs.pack_params("cpu")[0].item() == pytest.approx(0.6)
+        scene.sdfs[0].radius.data.fill_(2.0)
+        assert cs.pack_params("cpu")[0].item() == 2.0
+    opt = torch.optim.SGD(scene.parameters(), lr=1.0)
+    scene.sdfs[0].radius.grad = torch.tensor(0.5)
+    opt.step()
+    assert cs.pack_params("cpu")[0].item() == 1.5
+    # the in-kernel gather table follows the parameter storages: same object while they stay put, rebuilt when a
+    # parameter is re-allocated; rows = {pointer, element | dtype << 32} per float
+    t1 = cs.param_table("cpu")
+    assert t1 is cs.param_table("cpu") and t1.shape == (2 * cs.n_params,)
+    rows = t1.view(-1, 2)
+    assert rows[0, 0].item() == scene.sdfs[0].radius.data_ptr() and rows[0, 1].item() == 0
+    off = cs.leaf_offsets[5]
+    assert rows[off + 2, 0].item() == scene.sdfs[1].sdfs[2].start.data_ptr() and rows[off + 2, 1].item() == 2
+    scene.sdfs[0].radius.data = torch.tensor(0.25)
+    t2 = cs.param_table("cpu")
+    assert t2 is not t1 and t2.view(-1, 2)[0, 0].item() == scene.sdfs[0].radius.data_ptr()
+    scene.half()
+    assert (cs.param_table("cpu").view(-1, 2)[:, 1] >> 32 == 1).all()           # RM_DTYPE_F16
+    scene.double()
+    assert cs.param_table("cpu") is None                                          # not readable in place: caller packs
+
+
+def test_modules_deepcopy_and_pickle_after_compile(tmp_path):
+    """the compile cache (ctypes library handles, device tensors) must not sit in the module's state:
+    copy.deepcopy (EMA copies) and torch.save / torch.load of a whole scene or RenderLoop work after a compile."""
+    import copy
+    import pickle
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.scene import scene_registry as R
+    scene = R.make_closed_test_scene()
+    cs = compiled_for(scene)
+    cs.lib()                                   # resolve the library handle like a first render does
+    loop = RenderLoop(scene, num_cameras=1, px_width=8, px_height=6)
+    loop.normals.tetra()
+    loop._f32_cache["x"] = ("k", torch.zeros(1))
+    twin = copy.deepcopy(scene)
+    assert [n for n, _ in twin.named_parameters()] == [n for n, _ in scene.named_parameters()]
+    assert compiled_for(twin) is not cs and compiled_for(twin).signature == cs.signature
+    loop2 = copy.deepcopy(loop)
+    assert loop2._f32_cache == {} and loop2.scene is not scene
+    path = tmp_path / "loop.pt"
+    torch.save(loop, path)
+    loop3 = torch.load(path, weights_only=False)          # a file this test wrote itself
+    assert torch.equal(loop3.camera.ray_directions, loop.camera.ray_directions)
+    assert torch.equal(loop3.scene.blend_k if hasattr(loop3.scene, "blend_k") else loop3.scene.sdfs[0].blend_k,
+                       scene.sdfs[0].blend_k)
+    cs2 = pickle.loads(pickle.dumps(cs))                  # a CompiledScene travels as its program only
+    assert cs2._lib is None and cs2._table == {} and (cs2.program == cs.program).all()
 
 
 def test_compiler_cull_placement_and_evaluation_order(monkeypatch):
