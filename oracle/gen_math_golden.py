@@ -27,13 +27,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "math_sweep.json"))
     ap.add_argument("--blocks", type=int, default=256)
+    ap.add_argument("--only", nargs="*", help="regenerate these functions only, keep the rest of the file")
     args = ap.parse_args()
     math_ref.build(force=True)
     cpu = subprocess.run("lscpu | grep 'Model name' | cut -d: -f2", shell=True, capture_output=True, text=True).stdout.strip()
     out = {"host": {"cpu": cpu, "torch": torch.__version__, "capability": torch.backends.cpu.get_cpu_capability(),
                     "machine": platform.machine()},
            "block": math_ref.BLOCK, "checksum": "sum canon(out_bits) * (2 i + 1) mod 2^64", "functions": {}}
-    for fn in math_ref.FN:
+    if args.only and os.path.isfile(args.out):
+        with open(args.out) as f:
+            out["functions"] = json.load(f)["functions"]
+    for fn in (args.only or math_ref.FN):
         t0 = time.time()
         rows = {"ours": [], "torch": [], "n_diff": [], "max_ulp": []}
         for blk in range(args.blocks):
@@ -42,6 +46,8 @@ def main():
             s, osum, nd, mu = math_ref.sweep_block(fn, blk, ref)
             rows["ours"].append(f"{s:016x}"); rows["torch"].append(f"{osum:016x}")
             rows["n_diff"].append(nd); rows["max_ulp"].append(mu)
+        if fn in math_ref.CHECKED_BLOCKS:
+            rows["checked_blocks"] = math_ref.CHECKED_BLOCKS[fn]
         rows["total_diff"] = sum(rows["n_diff"])
         rows["worst_ulp"] = max(rows["max_ulp"])
         out["functions"][fn] = rows

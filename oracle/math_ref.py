@@ -11,7 +11,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "_build", "librm_math_ref.so")
-FN = {"exp": 0, "log": 1, "pow_gamma": 2, "atan2": 3}
+FN = {"exp": 0, "log": 1, "pow_gamma": 2, "atan2": 3, "sqrt": 4}
+# sqrt: the device function is specified for |x| >= 2^-95 (below, v_sqrt_f32 flushes denormal inputs and the FMA
+# residuals underflow): blocks 0x00-0x0f and 0x80-0x8f are not compared
+CHECKED_BLOCKS = {"sqrt": [[0x10, 0x80], [0x90, 0x100]]}
 BLOCK = 1 << 24
 GAMMA = float(torch.tensor(1 / 2.33, dtype=torch.float32))   # the shader's exponent as ATen sees it
 
@@ -34,7 +37,7 @@ def lib():
         _lib.rm_sweep_block.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int64)]
         _lib.rm_sweep_inputs.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
-        for name in ("ref_expf_v", "ref_logf_v"):
+        for name in ("ref_expf_v", "ref_logf_v", "ref_sqrtf_v"):
             getattr(_lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         for name in ("ref_powf_v", "ref_atan2f_v"):
             getattr(_lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
@@ -58,6 +61,7 @@ def _binary(name, a, b):
 
 def expf(x): return _unary("ref_expf_v", x)
 def logf(x): return _unary("ref_logf_v", x)
+def sqrtf(x): return _unary("ref_sqrtf_v", x)
 def powf(x, y): return _binary("ref_powf_v", x, torch.as_tensor(y, dtype=torch.float32))
 def atan2f(y, x): return _binary("ref_atan2f_v", y, x)
 
@@ -75,6 +79,8 @@ def torch_eval(fn: str, a, b):
         return torch.exp(a)
     if fn == "log":
         return torch.log(a)
+    if fn == "sqrt":
+        return a.pow(1 / 2)              # shader.py:116 (ATen dispatches exponent 0.5 to its sqrt kernel = MKL vsSqrt)
     if fn == "pow_gamma":
         return a.pow(1 / 2.33)           # shader.py:37
     return torch.atan2(a, b)             # shader.py:99 (imag, real)

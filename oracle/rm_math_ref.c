@@ -23,19 +23,19 @@ static inline float bitsf(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 
 /* ---- exp / log through double precision ----------------------------------------------------------- */
 float ref_expf(float x) {
+  if (x != x) return x;
+  if (x < -104.0f) return 0.0f;
+  if (x > 89.0f) return INFINITY;
   double xd = (double)x;
-  if (x > 89.0f) xd = 89.0;
-  if (x < -110.0f) xd = -110.0;
   double k = rint(xd * 0x1.71547652b82fep+0);
   double r = fma(k, -0x1.62e42fefa0000p-1, xd);
   r = fma(k, -0x1.cf79abc9e3b3ap-40, r);
-  static const double c[] = {0x1.ae64567f544e4p-26, 0x1.27e4fb7789f5cp-22, 0x1.71de3a556c734p-19,
+  static const double c[] = {0x1.27e4fb7789f5cp-22, 0x1.71de3a556c734p-19,
                              0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-13, 0x1.6c16c16c16c17p-10,
                              0x1.1111111111111p-7,  0x1.5555555555555p-5,  0x1.5555555555555p-3,
                              0.5, 1.0, 1.0};
   double p = c[0];
-  for (int i = 1; i < 12; ++i) p = fma(p, r, c[i]);
-  if (k != k) return x;                   /* NaN in, NaN out (ldexp needs an int) */
+  for (int i = 1; i < 11; ++i) p = fma(p, r, c[i]);
   return (float)ldexp(p, (int)k);
 }
 
@@ -206,7 +206,11 @@ float ref_atan2f(float y, float x) {       /* xatan2f_u1 */
  * Input i (0 .. 2^32-1) of a unary sweep is the float with bit pattern i; of the atan2 sweep the pair
  * (y, x) = (bits hash_y(i), bits hash_x(i)).  A block is 2^24 consecutive inputs.  Checksum of a block =
  * sum over its inputs of canon(out_bits) * (2 i + 1) mod 2^64 (NaNs canonicalised to 0x7fc00000). */
-enum { REF_EXP = 0, REF_LOG = 1, REF_POW_GAMMA = 2, REF_ATAN2 = 3 };
+enum { REF_EXP = 0, REF_LOG = 1, REF_POW_GAMMA = 2, REF_ATAN2 = 3, REF_SQRT = 4 };
+
+/* IEEE square root.  ATen's vector_norm ends in it; the shaders' brightness .pow(1/2) (shader.py:116) is MKL VML
+ * vsSqrt instead, which is not correctly rounded -- the sweep records how often this host's torch.sqrt differs. */
+float ref_sqrtf(float x) { return sqrtf(x); }
 
 uint32_t rm_sweep_hash_y(uint32_t i) { uint32_t h = i * 0x9E3779B1u + 0x7F4A7C15u; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; return h; }
 uint32_t rm_sweep_hash_x(uint32_t i) { uint32_t h = (i ^ 0x85EBCA6Bu) * 0xC2B2AE35u; h ^= h >> 13; h *= 0x297A2D39u; h ^= h >> 16; return h; }
@@ -217,6 +221,7 @@ static inline float sweep_eval(int fn, uint32_t i) {
     case REF_EXP: return ref_expf(bitsf((int32_t)i));
     case REF_LOG: return ref_logf(bitsf((int32_t)i));
     case REF_POW_GAMMA: return ref_powf(bitsf((int32_t)i), (float)(1 / 2.33));
+    case REF_SQRT: return ref_sqrtf(bitsf((int32_t)i));
     default: return ref_atan2f(bitsf((int32_t)rm_sweep_hash_y(i)), bitsf((int32_t)rm_sweep_hash_x(i)));
   }
 }
@@ -265,6 +270,7 @@ uint64_t rm_sweep_block(int fn, uint32_t block, const float* other, uint64_t* ot
 
 /* plain array forms (tests) */
 void ref_expf_v(const float* a, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = ref_expf(a[i]); }
+void ref_sqrtf_v(const float* a, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = ref_sqrtf(a[i]); }
 void ref_logf_v(const float* a, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = ref_logf(a[i]); }
 void ref_powf_v(const float* a, const float* b, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = ref_powf(a[i], b[i]); }
 void ref_atan2f_v(const float* a, const float* b, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = ref_atan2f(a[i], b[i]); }

@@ -22,11 +22,17 @@ HIPCC_FLAGS_FAST = ["--offload-arch=gfx950", "-O3", "-ffp-contract=fast", "-DRM_
 LIB_PATH_FAST = os.path.join(LIBDIR, "librm_hip_fast.so")
 
 
+def extra_flags():
+    """Experiment knob: RM_HIPCC_EXTRA="-DRM_..." adds compile flags (A/B probes, profiles/ab_probe.py); the
+    flags are part of every library's staleness / cache key, so variants never mix."""
+    return os.environ.get("RM_HIPCC_EXTRA", "").split()
+
+
 def variant(precision: str):
     if precision == "exact":
-        return LIB_PATH, HIPCC_FLAGS
+        return LIB_PATH, HIPCC_FLAGS + extra_flags()
     if precision == "fast":
-        return LIB_PATH_FAST, HIPCC_FLAGS_FAST
+        return LIB_PATH_FAST, HIPCC_FLAGS_FAST + extra_flags()
     raise ValueError(f"precision must be 'exact' or 'fast', not {precision!r}")
 
 
@@ -42,6 +48,7 @@ def sources_hash() -> str:
     for s in SOURCES:
         with open(s, "rb") as f:
             h.update(f.read())
+    h.update(" ".join(extra_flags()).encode())
     return h.hexdigest()
 
 

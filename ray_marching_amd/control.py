@@ -9,6 +9,8 @@ pyautogui (the reference's control.py does, at import time: control.py:3-4,14).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -17,6 +19,9 @@ from . import ops
 from .compiler import compiled_for
 from .rendering.ray_marching import PinholeCamera, SDFMarcher, SDFNormals
 from .rendering.shader import Shader
+
+
+_AB_PACK = bool(os.environ.get("RM_AB_PACK"))      # experiment knob: pack the parameters for inference frames too
 
 
 class CapturedFrame:
@@ -174,7 +179,7 @@ class RenderLoop(nn.Module):
         cmap = self._cmap(rp.device) if mode in (6, 7) else None
         # training frames pack the parameters with torch.cat (the autograd edge back to every nn.Parameter);
         # inference frames let the kernel gather them from the parameter storages (nothing to go stale)
-        params = cs.pack_params(rp.device) if training else None
+        params = cs.pack_params(rp.device) if (training or _AB_PACK) else None
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,

@@ -44,27 +44,14 @@ RM_DEV float dot_seq(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RM_DEV V3 cross(V3 a, V3 b) {
   return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-// Correctly rounded sqrt (ATen CPU = IEEE sqrt): v_sqrt_f32 is 1 ulp, so test the two
-// neighbours with exact FMA residuals and step to the one that brackets x (the correction
-// step of LLVM's own f32 sqrt expansion).  0, inf, NaN and negatives fall through unchanged
-// because every comparison with a NaN residual is false.  Unlike sqrtf() the input is not
-// pre-scaled, so for x < 2^-96 (|p| < 1e-14) the residuals underflow and the result may keep
-// v_sqrt's 1-ulp error; 9 instructions instead of 15.  (hipcc lowers __fsqrt_rn to the bare
-// 1-ulp v_sqrt_f32 -- it is NOT correctly rounded; measured, see DESIGN.md.)
+// Correctly rounded sqrt (rm_math.h: sqrt_rn); the opt-in fast build takes the bare 1-ulp v_sqrt_f32.
 RM_DEV float rm_sqrt(float x) {
 #if defined(RM_FAST_MATH)
-  return __builtin_amdgcn_sqrtf(x);   // opt-in "fast" build: bare v_sqrt_f32 (1 ulp), see DESIGN.md
+  return __builtin_amdgcn_sqrtf(x);
 #elif defined(RM_LIBM_SQRT)
   return __builtin_sqrtf(x);
 #else
-  float r = __builtin_amdgcn_sqrtf(x);
-  float lo = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1);
-  float hi = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
-  float elo = __builtin_fmaf(-lo, r, x);
-  float ehi = __builtin_fmaf(-hi, r, x);
-  r = (elo <= 0.0f) ? lo : r;
-  r = (ehi > 0.0f) ? hi : r;
-  return r;
+  return sqrt_rn(x);
 #endif
 }
 // exp / log / pow / atan2 (rm_math.h).  torch's CPU exp and log are MKL VML (closed source, and the bits depend
@@ -74,6 +61,8 @@ RM_DEV float rm_sqrt(float x) {
 RM_DEV float rm_exp(float x) {
 #if defined(RM_FAST_MATH)
   return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#elif defined(RM_AB_OCML_EXPLOG)
+  return expf(x);
 #else
   return exp_f64path(x);
 #endif
@@ -81,19 +70,21 @@ RM_DEV float rm_exp(float x) {
 RM_DEV float rm_log(float x) {
 #if defined(RM_FAST_MATH)
   return __builtin_amdgcn_logf(x) * 0.693147180559945309417f;
+#elif defined(RM_AB_OCML_EXPLOG)
+  return logf(x);
 #else
   return log_f64path(x);
 #endif
 }
 RM_DEV float rm_pow(float x, float y) {
-#if defined(RM_FAST_MATH)
+#if defined(RM_FAST_MATH) || defined(RM_AB_OCML_SHADER)
   return powf(x, y);
 #else
   return sleef_powf(x, y);
 #endif
 }
 RM_DEV float rm_atan2(float y, float x) {
-#if defined(RM_FAST_MATH)
+#if defined(RM_FAST_MATH) || defined(RM_AB_OCML_SHADER)
   return atan2f(y, x);
 #else
   return sleef_atan2f(y, x);

@@ -595,7 +595,11 @@ RM_DEV Shaded domain_colour(float re, float im, int size, int degree) {
 // brightness.mul(colours) (shader.py:118): fp32 brightness times a float64 colormap row is a float64 product
 // (type promotion), times an fp32 / fp16 row a product in that type.
 RM_DEV void store_shaded(void* image, int image_dt, int64_t li, const Shaded& s, const void* cmap, int cmap_dt) {
-  if (s.idx < 0) { store3_t(image, li, s.rgb, image_dt); return; }
+  if (s.idx < 0) {
+    if (image_dt == RM_DTYPE_F32) store3(static_cast<float*>(image), li, s.rgb);
+    else store3_t(image, li, s.rgb, image_dt);
+    return;
+  }
   if (cmap_dt == RM_DTYPE_F64) {
     const double* c = static_cast<const double*>(cmap) + 3 * (int64_t)s.idx;
     const double b = (double)s.bright;
@@ -732,6 +736,21 @@ struct TileRays {
   bool live;
 };
 
+// camera-frame ray + pose of one lane, element type T: every load is issued before the first use, so one
+// memory latency is paid per tile (a typed load behind its own dtype branch would wait separately each time)
+template <class T>
+RM_DEV void load_ray_and_pose(const RenderArgs& a, int64_t gi, int cam, V3& o, V3& v, Pose& ps) {
+  const T* rp = static_cast<const T*>(a.cam.ray_positions) + 3 * gi;
+  const T* rd = static_cast<const T*>(a.cam.ray_directions) + 3 * gi;
+  const T* q = static_cast<const T*>(a.orientation) + 4 * cam;
+  const T* t = static_cast<const T*>(a.translation) + 3 * cam;
+  const T o0 = rp[0], o1 = rp[1], o2 = rp[2], v0 = rd[0], v1 = rd[1], v2 = rd[2];
+  const T q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], t0 = t[0], t1 = t[1], t2 = t[2];
+  o = mk3((float)o0, (float)o1, (float)o2);
+  v = mk3((float)v0, (float)v1, (float)v2);
+  ps.w = (float)q0; ps.qv = mk3((float)q1, (float)q2, (float)q3); ps.t = mk3((float)t0, (float)t1, (float)t2);
+}
+
 RM_DEV TileRays load_tile_rays(const RenderArgs& a, int64_t tile) {
   const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
   TileRays r;
@@ -740,10 +759,12 @@ RM_DEV TileRays load_tile_rays(const RenderArgs& a, int64_t tile) {
   if (!r.live) { cam = 0; row = 0; col = 0; }
   r.li = ((int64_t)cam * rows + row) * W + col;                          // index in the band outputs
   int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;       // index in the camera buffers
-  r.ps = load_pose(a.orientation, a.translation, cam, a.cam.dtype);
+  V3 o, v;
+  if (a.cam.dtype == RM_DTYPE_F16) load_ray_and_pose<_Float16>(a, gi, cam, o, v, r.ps);
+  else load_ray_and_pose<float>(a, gi, cam, o, v, r.ps);
   // PinholeCamera.forward (ray_marching.py:58-62)
-  r.o = qrot(load3_t(a.cam.ray_positions, gi, a.cam.dtype), r.ps.w, r.ps.qv) + r.ps.t;
-  r.v = qrot(load3_t(a.cam.ray_directions, gi, a.cam.dtype), r.ps.w, r.ps.qv);
+  r.o = qrot(o, r.ps.w, r.ps.qv) + r.ps.t;
+  r.v = qrot(v, r.ps.w, r.ps.qv);
   return r;
 }
 

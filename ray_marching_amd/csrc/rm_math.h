@@ -12,7 +12,8 @@
 //     bits on the Intel build container and on the GPU box's AMD EPYC host (profiles/host_math_probe.py), so
 //     "the reference's exp/log bits" do not exist as a single target.  rm_exp / rm_log therefore compute the
 //     value both MKL variants approximate -- the correctly rounded result -- through fp64 arithmetic
-//     (error before the final rounding < 2^-46; fp64 FMA issues at the fp32 FMA rate on gfx950).  Against the
+//     (error before the final rounding < 2^-41: the result is the correctly rounded one except on ~1e-5 of inputs;
+//     an fp64 FMA issues in ~5.5 cycles per wave on gfx950, profiles/micro/f64_issue_bench.hip).  Against the
 //     build container's torch: exp differs on 1.5 % of inputs, log on 0.01 %, never by more than 1 ulp;
 //     exhaustive per-block counts in tests/golden/math_sweep.json.
 #pragma once
@@ -28,17 +29,35 @@ RM_MDEV int f2i(float f) { return __builtin_bit_cast(int, f); }
 RM_MDEV float i2f(int i) { return __builtin_bit_cast(float, i); }
 
 // ---------------------------------------------------------------------------
+// Correctly rounded square root (= IEEE sqrtf = what ATen's vector_norm ends in): v_sqrt_f32 is 1 ulp, so test
+// the two neighbours with exact FMA residuals and step to the one that brackets x (the correction step of LLVM's
+// own f32 sqrt expansion; hipcc lowers __fsqrt_rn to the bare v_sqrt_f32 -- NOT correctly rounded, measured).
+// 0, inf, NaN and negatives fall through unchanged because every comparison with a NaN residual is false.  The
+// input is not pre-scaled, so below 2^-96 (|p| < 1e-14, never on the path) the residuals underflow and the result
+// may keep v_sqrt's 1-ulp error; 9 instructions instead of 15.  Exhaustively equal to sqrtf for every x >= 2^-95
+// (tests/test_math_sweep.py).  NB the shaders' brightness .pow(1/2) (shader.py:116) is MKL VML vsSqrt in ATen,
+// which is NOT correctly rounded (0.6 % of inputs 1 ulp off, host dependent): same situation as exp / log.
+// ---------------------------------------------------------------------------
+RM_MDEV float sqrt_rn(float x) {
+  float r = __builtin_amdgcn_sqrtf(x);
+  float lo = i2f(f2i(r) - 1);
+  float hi = i2f(f2i(r) + 1);
+  float elo = __builtin_fmaf(-lo, r, x);
+  float ehi = __builtin_fmaf(-hi, r, x);
+  r = (elo <= 0.0f) ? lo : r;
+  r = (ehi > 0.0f) ? hi : r;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
 // exp / log through fp64
 // ---------------------------------------------------------------------------
 RM_MDEV float exp_f64path(float x) {
-  double xd = (double)x;
-  xd = (x > 89.0f) ? 89.0 : xd;          // overflows to +inf in the final conversion
-  xd = (x < -110.0f) ? -110.0 : xd;      // rounds to +0 (NaN fails both tests and flows through)
+  const double xd = (double)x;
   const double k = __builtin_rint(xd * 0x1.71547652b82fep+0);
   double r = __builtin_fma(k, -0x1.62e42fefa0000p-1, xd);   // ln2 split: k * hi is exact
   r = __builtin_fma(k, -0x1.cf79abc9e3b3ap-40, r);          // |r| <= 0.3466
-  double p = 0x1.ae64567f544e4p-26;                          // 1/11!  (Taylor: remainder r^12/12! < 2^-47)
-  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);            // 1/10!
+  double p = 0x1.27e4fb7789f5cp-22;                          // 1/10!  (Taylor: remainder r^11/11! < 2^-42)
   p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);            // 1/9!
   p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);            // 1/8!
   p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);            // 1/7!
@@ -49,7 +68,12 @@ RM_MDEV float exp_f64path(float x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return (float)__builtin_ldexp(p, (int)k);                  // one rounding, subnormal results included
+  float out = (float)__builtin_ldexp(p, (int)k);             // one rounding, subnormal results included
+  // outside [-104, 89] the lines above produce garbage (k saturates, r is meaningless): the results there
+  // are 0 and +inf; NaN fails both comparisons and has already propagated through p
+  out = (x < -104.0f) ? 0.0f : out;
+  out = (x > 89.0f) ? __builtin_inff() : out;
+  return out;
 }
 
 RM_MDEV float log_f64path(float x) {

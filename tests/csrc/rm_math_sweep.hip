@@ -14,7 +14,8 @@ __device__ __forceinline__ float eval(int fn, float a, float b) {
     case 0: return rm::exp_f64path(a);
     case 1: return rm::log_f64path(a);
     case 2: return rm::sleef_powf(a, b);
-    default: return rm::sleef_atan2f(a, b);
+    case 3: return rm::sleef_atan2f(a, b);
+    default: return rm::sqrt_rn(a);
   }
 }
 
@@ -48,13 +49,13 @@ extern "C" {
 
 // sums: device uint64[n_blocks], zeroed by the caller
 int rm_math_sweep(int fn, uint32_t block_begin, uint32_t n_blocks, float gamma, unsigned long long* sums, void* stream) {
-  if (fn < 0 || fn > 3 || !sums || n_blocks == 0 || block_begin + n_blocks > 256) return -1;
+  if (fn < 0 || fn > 4 || !sums || n_blocks == 0 || block_begin + n_blocks > 256) return -1;
   k_sweep<<<n_blocks * kGroupsPerBlock, 256, 0, (hipStream_t)stream>>>(fn, block_begin, gamma, sums);
   return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int rm_math_eval(int fn, const float* a, const float* b, float* out, long long n, void* stream) {
-  if (fn < 0 || fn > 3 || !a || !out || n < 0 || (fn >= 2 && !b)) return -1;
+  if (fn < 0 || fn > 4 || !a || !out || n < 0 || ((fn == 2 || fn == 3) && !b)) return -1;
   if (n == 0) return 0;
   long long g = (n + 255) / 256;
   k_eval<<<(int)(g < 4096 ? g : 4096), 256, 0, (hipStream_t)stream>>>(fn, a, b, out, n);

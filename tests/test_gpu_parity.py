@@ -148,12 +148,15 @@ def test_frames_vs_golden(name, early, kernel_path):
         got = img[..., : want.shape[-1]]
         mx, frac = H.report(f"{name} mode{m}", got, want)
         print(f"{name} mode {m} early={early}: max|err|={mx:.3g} frac>1e-5={frac:.3g}")
-        if m in (6, 7):
-            assert img.dtype == torch.float64      # fp32 brightness * float64 colormap (shader.py:104,118)
         assert mx <= TOL, (name, m, mx)
-        if exact_scene:
-            # every mode, the image itself: atan2 / pow are Sleef's bits, the distance shaders' log lands on
-            # MKL's value for these pixels, the colormap product is taken in float64
+        if m in (6, 7):
+            # fp32 brightness * float64 colormap row = float64 image (shader.py:104,118).  The colormap index
+            # (Sleef atan2) is exact; the brightness .pow(1/2) (shader.py:116) is MKL vsSqrt in ATen, which is
+            # not correctly rounded (0.6 % of inputs 1 ulp off, tests/golden/math_sweep.json) -- the kernel's
+            # IEEE sqrt may therefore sit one fp32 ulp of the brightness away, nothing more
+            assert img.dtype == torch.float64 and mx <= 1.2e-7, (name, m, mx)
+        elif exact_scene:
+            # the image itself: pow is Sleef's bits, the distance shaders' log lands on MKL's value for these pixels
             assert mx == 0.0, f"mode {m} on scene2 expected bit-exact, got {mx}"
     # intermediate tensors through the stand-alone modules (marcher / normals / scene call)
     with torch.no_grad():

@@ -1,4 +1,4 @@
-"""exp / log / pow / atan2 of the path: device function == CPU restatement == (where a single target exists) torch.
+"""exp / log / pow / atan2 / sqrt of the path: device function == CPU restatement == (where a single target exists) torch.
 
 tests/golden/math_sweep.json (oracle/gen_math_golden.py, build container) holds, per block of 2^24 inputs and
 for all 2^32 inputs of each function, the checksum of oracle/rm_math_ref.c, the checksum of torch's CPU result on
@@ -40,6 +40,7 @@ def test_fixture_is_exhaustive_and_sleef_functions_match_torch(gold):
     # MKL VML inside ATen: no single target; the recorded distance from the generating host's bits
     assert gold["functions"]["exp"]["total_diff"] < 0.0025 * 2 ** 32
     assert gold["functions"]["log"]["total_diff"] < 1e-5 * 2 ** 32
+    assert gold["functions"]["sqrt"]["total_diff"] < 0.0035 * 2 ** 32       # vsSqrt(HA) is not correctly rounded
 
 
 SAMPLE_BLOCKS = [0x00, 0x3f, 0x40, 0x42, 0x7f, 0x80, 0xbf, 0xc1, 0xff]
@@ -105,7 +106,8 @@ def test_device_functions_reproduce_every_checksum(fn, gold, sweep_lib):
     torch.cuda.synchronize()
     got = [f"{v & 0xffffffffffffffff:016x}" for v in sums.cpu().tolist()]
     want = gold["functions"][fn]["ours"]
-    bad = [i for i in range(256) if got[i] != want[i]]
+    ranges = gold["functions"][fn].get("checked_blocks", [[0, 256]])     # sqrt_rn is specified for |x| >= 2^-95
+    bad = [i for lo, hi in ranges for i in range(lo, hi) if got[i] != want[i]]
     assert not bad, f"{fn}: device differs from the restatement in blocks {[hex(b) for b in bad[:16]]} ({len(bad)} of 256)"
     if fn in ("pow_gamma", "atan2"):
         assert got == gold["functions"][fn]["torch"]     # hence bit-identical with ATen (Sleef) on every input
@@ -119,10 +121,14 @@ def test_device_special_values(sweep_lib):
     ad, bd = a.cuda(), b.cuda()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for fn, ref in (("exp", math_ref.expf(a)), ("log", math_ref.logf(a)), ("pow_gamma", math_ref.powf(a, b)),
-                    ("atan2", math_ref.atan2f(a, b))):
+                    ("atan2", math_ref.atan2f(a, b)), ("sqrt", math_ref.sqrtf(a))):
+        if fn == "sqrt":           # below 2^-95 the device function is not specified
+            ref = torch.where(a.abs() < 2.0 ** -95, torch.zeros_like(ref), ref)
         out = torch.empty_like(ad)
         assert sweep_lib.rm_math_eval(math_ref.FN[fn], C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()),
                                       C.c_void_p(out.data_ptr()), ad.numel(), stream) == 0
         got = out.cpu()
+        if fn == "sqrt":
+            got = torch.where(a.abs() < 2.0 ** -95, torch.zeros_like(got), got)
         same = (got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))
         assert bool(same.all()), (fn, a[~same], b[~same], got[~same], ref[~same])
