@@ -68,7 +68,7 @@ enum {
   RM_OP_UNION_END = 11,    /* aux0 = first tape slot, aux1 = child count */
   RM_OP_SMOOTH_BEGIN = 12, /*                               transformations.py:67-71 */
   RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot */
-  RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count */
+  RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count; slot aux0+aux1 holds the logsumexp */
   RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
   RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
   RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: aux0 = derived offset of its bound, 5 floats
@@ -252,7 +252,16 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
                        float* grad_pos /*nullable [R,3]*/, float* grad_dirs /*nullable [R,3]*/,
                        int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags,
-                       void* stream);
+                       int32_t* tile_cost /*nullable out [T]: reverse march steps each tile's wave walked*/,
+                       float* hard_ws /*nullable: rm_bwd_hard_floats(hard_capacity, steps) floats*/,
+                       int64_t hard_capacity, void* stream);
+
+/* Workspace of the deferred-ray path of rm_render_backward.  Rays whose march has not converged need a VJP at
+ * every remaining step; walked by their own wave they are the critical path of the launch, so (with
+ * RM_FLAG_EARLY_OUT and a `work` buffer) up to hard_capacity of them are put on a list and all their
+ * (ray, step) pairs are evaluated in parallel by three follow-up kernels.  Rays beyond the capacity are walked
+ * in place; hard_ws = NULL switches the path off.  Same gradients either way (to summation order). */
+int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps);
 
 /* VJP of PinholeCamera.forward (rendering/ray_marching.py:57-64) w.r.t. the pose: reduces per-ray
  * gradients grad_pos / grad_dirs ([N,rows,W,3], either may be NULL) to grad_orientation [N,4] and

@@ -242,8 +242,8 @@ def _emit(node, em: _Emitter, n_params: int):
             raise NotImplementedError("SDFSmoothUnion with 512 or more children: ATen's sum kernel switches to cascade "
                                       "levels there, which the kernels' summation order (aten_inner_sum) does not follow")
         base = em.n_slots
-        em.n_slots += len(kids)
         smooth = kind == "smooth_union"
+        em.n_slots += len(kids) + (1 if smooth else 0)     # smooth union: one more slot for the logsumexp value
         koff = em.off(node.blend_k) if smooth else 0
         em.ins(A.OP_SMOOTH_BEGIN if smooth else A.OP_UNION_BEGIN)
         em.push(_STACK_SMOOTH if smooth else _STACK_UNION)

@@ -29,7 +29,9 @@ int fail(int code, const char* fmt, ...) {
 }
 
 constexpr int kMaxBlocks = 2048;        // persistent grid cap: 256 CUs x 8 blocks
-constexpr int kMaxBlocksBwd = 1024;     // also the partials row count
+constexpr int kMaxBlocksBwd = 1024;     // rows of per-block partial sums a backward kernel may write
+constexpr int kHardBlocksB = 1024;      // + rows of k_bwd_hard_b (deferred rays)
+constexpr int kPartialRows = kMaxBlocksBwd + kHardBlocksB;
 constexpr size_t kLdsDefault = 64 * 1024;
 constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
 
@@ -107,6 +109,15 @@ int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+bool env_set(const char* name) { const char* v = getenv(name); return v && *v; }
+int cu_count() {
+  static int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
 int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
 // frame kernel: 1280 blocks x 4 waves = 5 waves/SIMD measured best with the atomic tile queues
 // (profiles/grid_sweep.py: 512 -> 463 us, 1024 -> 376, 1280 -> 371, 2048 -> 390)
@@ -118,12 +129,12 @@ int launched(const char* what) {
   return RM_OK;
 }
 
-// partials holds kMaxBlocksBwd rows of per-block sums followed by one row of totals
+// partials holds kPartialRows rows of per-block sums followed by one row of totals
 int reduce_partials(const RmScene& sc, float* partials, int nblocks, float* grad_params, hipStream_t s) {
   if (!grad_params) return RM_OK;
   const int n_acc = sc.n_params + sc.n_derived;
   if (n_acc == 0) return RM_OK;
-  float* sums = partials + (size_t)kMaxBlocksBwd * n_acc;
+  float* sums = partials + (size_t)kPartialRows * n_acc;
   rm::k_reduce_partials<<<n_acc, 256, 0, s>>>(partials, nblocks, n_acc, sums);
   if (int e = launched("k_reduce_partials")) return e;
   size_t lds = 4 * (size_t)(n_acc + 1);
@@ -142,7 +153,12 @@ const char* rm_last_error(void) { return g_err; }
 int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
   if (!scene) return 0;
   (void)n;
-  return (int64_t)(kMaxBlocksBwd + 1) * (scene->n_params + scene->n_derived);
+  return (int64_t)(kPartialRows + 1) * (scene->n_params + scene->n_derived);
+}
+
+int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps) {
+  if (capacity <= 0 || steps < 0) return 0;
+  return capacity * (2 + 8) + (int64_t)steps * capacity * 5;      // ray, step, state[8]; n[steps][cap][4], g[steps][cap]
 }
 
 int rm_sdf_forward(const RmScene* scene, const void* points, void* dist, int64_t n, int32_t dtype, void* stream) {
@@ -301,6 +317,20 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
+  if (tune_max_blocks() > 0 && (flags & RM_FLAG_DYNAMIC_TILES) && minmax && !env_set("RM_MAX_BLOCKS")) {
+    // Persistent grid, two more limits (measured, profiles/ab_probe.py): (1) never more blocks than the chip
+    // holds at once -- a block that starts late pays the scene staging for an empty queue (the 32-primitive
+    // kernel is register-limited to fewer than 5 waves per SIMD: 1280 -> 512 blocks, 14.2 -> 13.05 ms per 8K
+    // band); (2) at least ~2 tiles per wave, or the dynamic queues have nothing to balance with (512^2 frame,
+    // closed scene 1: 1280 -> 512 blocks, 228 -> 177 us).
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<G>, L.block, L.lds) == hipSuccess && per_cu > 0) {
+      const int resident = per_cu * cu_count();
+      if (grid > resident) grid = resident;
+    }
+    const int64_t two_per_wave = (wave_tiles / 2 + (L.block >> 6) - 1) / (L.block >> 6);
+    if (grid > two_per_wave) grid = (int)(two_per_wave < 1 ? 1 : two_per_wave);
+  }
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   return launched("k_render_fwd");
 }
@@ -397,7 +427,8 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
                        float* grad_pos, float* grad_dirs, int32_t mode,
-                       int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, void* stream) {
+                       int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, int32_t* tile_cost,
+                       float* hard_ws, int64_t hard_capacity, void* stream) {
 #ifdef RM_NO_BACKWARD
   return fail(RM_E_BADARG, "rm_render_backward: this specialised library was built forward-only");
 #else
@@ -412,7 +443,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
   a.grad_image = grad_image; a.partials = partials; a.minmax = work;
-  a.grad_pos = grad_pos; a.grad_dirs = grad_dirs;
+  a.grad_pos = grad_pos; a.grad_dirs = grad_dirs; a.tile_cost = tile_cost;
   a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
   if (int e = pick_launch(rm::k_render_bwd<GB>, *scene, true, 128, &L)) return e;
@@ -423,9 +454,36 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                                            : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
   int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), kMaxBlocksBwd);
+  // deferred rays: only with the reverse early exit, a workspace for the list and its counter
+  const bool defer = hard_ws && hard_capacity > 0 && work && (flags & RM_FLAG_EARLY_OUT) && steps > 0;
+  if (defer) {
+    if (hard_capacity > (int64_t)1 << 30) return fail(RM_E_BADARG, "rm_render_backward: hard_capacity too large");
+    const int64_t cap = hard_capacity;
+    a.hard_cap = (int32_t)cap;
+    a.hard_ray = reinterpret_cast<int32_t*>(hard_ws);
+    a.hard_step = reinterpret_cast<int32_t*>(hard_ws + cap);
+    a.hard_state = hard_ws + 2 * cap;
+    a.hard_n = hard_ws + 10 * cap;
+    a.hard_g = hard_ws + 10 * cap + (int64_t)steps * cap * 4;
+  }
   rm::k_render_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
-  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
+  int rows = grid;
+  if (defer) {
+    Launch LN, LB;
+    if (int e = pick_launch(rm::k_bwd_hard_n<GB>, *scene, true, 128, &LN)) return e;
+    if (int e = pick_launch(rm::k_bwd_hard_b<GB>, *scene, true, 128, &LB)) return e;
+    rm::k_bwd_hard_n<GB><<<2 * kMaxBlocksBwd, LN.block, LN.lds, (hipStream_t)stream>>>(a);   // no accumulators: 4 waves / SIMD
+    if (int e = launched("k_bwd_hard_n")) return e;
+    rm::k_bwd_hard_a<<<(int)((hard_capacity + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    if (int e = launched("k_bwd_hard_a")) return e;
+    rm::RenderArgs b = a;
+    b.partials = partials + (size_t)rows * (scene->n_params + scene->n_derived);     // its rows follow k_render_bwd's
+    rm::k_bwd_hard_b<GB><<<kHardBlocksB, LB.block, LB.lds, (hipStream_t)stream>>>(b);
+    if (int e = launched("k_bwd_hard_b")) return e;
+    rows += kHardBlocksB;
+  }
+  return reduce_partials(*scene, partials, rows, grad_params, (hipStream_t)stream);
 #endif
 }
 
@@ -455,7 +513,8 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_UNION_BEGIN: depth_f += 1; depth_b += 2; break;
       case RM_OP_SMOOTH_BEGIN: depth_b += 2; break;
       case RM_OP_UNION_END: case RM_OP_SMOOTH_END:
-        if (a1 <= 0 || a0 < 0 || a0 + a1 > n_slots) return fail(RM_E_PROGRAM, "instr %d: slots out of range", i);
+        if (a1 <= 0 || a0 < 0 || a0 + a1 + (op == RM_OP_SMOOTH_END ? 1 : 0) > n_slots)
+          return fail(RM_E_PROGRAM, "instr %d: slots out of range", i);
         if (op == RM_OP_SMOOTH_END && a1 >= 512) return fail(RM_E_PROGRAM, "instr %d: smooth union of %d >= 512 children", i, a1);
         depth_f -= (op == RM_OP_UNION_END) ? 1 : 0; depth_b -= 2;
         values++;

@@ -276,36 +276,106 @@ __global__ void __launch_bounds__(256) k_march_fwd(RmScene sc, const void* __res
 // 4 eps (|l_x v_x| + |l_y v_y| + |l_z v_z|), it carries no information; the wave stops when that
 // holds for all 64 rays.  The reference keeps adding such noise terms; the difference is far
 // inside the 1e-4 gradient tolerance (tests: worst |grad error| unchanged at 1e-6 level).
-template <class SceneT>
+struct NoDefer {
+  RM_DEV bool operator()(int, V3, V3, bool) const { return false; }
+};
+
+#ifndef RM_BWD_INLINE_STEPS
+#define RM_BWD_INLINE_STEPS 3     // moving steps a wave still walks itself before handing its active rays over
+#endif
+
+// `defer(i, lambda, gv, active)`: called once, wave-wide, when more than RM_BWD_INLINE_STEPS non-converged steps
+// remain; returns (per lane) whether the ray was handed to the deferred-ray kernels, which then own its outputs.
+template <class SceneT, class DeferF = NoDefer>
 RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
-                        int64_t ray, int nexec, int steps, bool want_gv, V3& gv, bool early) {
+                        int64_t ray, int nexec, int steps, bool want_gv, V3& gv, bool early, int* walked = nullptr,
+                        DeferF defer = DeferF(), bool* deferred_out = nullptr) {
+  if (deferred_out) *deferred_out = false;
   // `gv` by reference and a flag, not an optional pointer: a pointer that may be null pins the vector in
   // scratch memory (a load + store + vmcnt(0) per step).  The iterate of the NEXT step is fetched before
   // this step's VJP, so its HBM/L2 latency hides behind ~1000 instructions instead of stalling the wave.
+  if (walked) *walked = 0;
   if (steps <= 0) return lam;               // no trajectory buffer at all in that case
-  V3 p_next = (steps - 1 < nexec) ? load3(traj + 3 * (int64_t)(steps - 1) * traj_stride, ray) : p_final;
-  for (int i = steps - 1; i >= 0; --i) {
-    float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
-    if (early) {
-      float bound = 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
-      if (__all(fabsf(gf) <= bound)) {
-        if (want_gv) {
-          // steps 0..i are skipped with lambda frozen: sum_i f(p_i) = (p_{i+1} - p_0).v / |v|^2
-          V3 pn = (i + 1 < nexec) ? load3(traj + 3 * (int64_t)(i + 1) * traj_stride, ray) : p_final;
-          V3 p0 = load3(traj, ray);
-          V3 dp = pn - p0;
-          float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
-          gv = gv + sumf * lam;
-        }
-        break;
-      }
+  int i = steps - 1;
+  auto iterate = [&](int k) { return (k < nexec) ? load3(traj + 3 * (int64_t)k * traj_stride, ray) : p_final; };
+  auto noise = [&](float gf) {              // |g| below the rounding-error bound of its own dot product
+    return fabsf(gf) <= 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
+  };
+  auto finish_frozen = [&](int k) {         // steps 0..k skipped with lambda frozen: sum_i f(p_i) = (p_{k+1} - p_0).v / |v|^2
+    if (!want_gv) return;
+    V3 dp = iterate(k + 1) - load3(traj, ray);
+    float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
+    gv = gv + sumf * lam;
+  };
+#ifndef RM_BWD_NO_TAIL
+  // Converged tail (`early` only).  Once the march has settled, every remaining iterate is the same point up to
+  // the last few ulps (a bitwise fixed point, a 2-4 cycle between neighbouring floats, or a ray creeping 1e-7
+  // per step along a wall), so grad f and df/dtheta there are the same for all those steps: the recursion
+  //   g_i = lambda.v,  lambda += g_i n,  dL/dtheta += g_i df/dtheta(p)        (n = grad_p f at the anchor)
+  // needs ONE point-gradient evaluation for n, a few flops per step, and ONE parameter VJP with the summed
+  // upstream G = sum g_i at the end -- instead of a full VJP per step (measured on config 4: the reverse sweep
+  // walked 24.6 steps per wave tile on average, nearly all of them inside this tail).  The anchor is renewed
+  // when some ray of the wave has moved more than tau = 1e-6 max(1, |p|) away from it; arguments of the VJP
+  // differ from the reference's by <= tau, far inside the 1e-4 gradient tolerance (tests: f5_backward).
+  while (early && i >= 0) {
+    const V3 anchor = iterate(i);
+    const float tau = 1e-6f * fmaxf(1.0f, fmaxf(fabsf(anchor.x), fmaxf(fabsf(anchor.y), fabsf(anchor.z))));
+    auto near_anchor = [&](V3 q) {
+      return fmaxf(fabsf(q.x - anchor.x), fmaxf(fabsf(q.y - anchor.y), fabsf(q.z - anchor.z))) <= tau;
+    };
+    // how many of the next steps down stay at the anchor (for every ray of the wave)?  at least two, or the
+    // plain per-step VJP below is cheaper
+    if (i < 1 || !__all(near_anchor(iterate(i - 1)))) break;
+    float f0;
+    const V3 n = scene.vjp_point(anchor, 1.0f, &f0);
+    float G = 0.0f;
+    bool done = false;
+    V3 p_i = anchor;
+    while (i >= 0 && __all(near_anchor(p_i))) {
+      const float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+      if (__all(noise(gf))) { done = true; break; }
+      G = G + gf;
+      if (want_gv) gv = gv + f0 * lam;
+      lam = lam + mk3(gf * n.x, gf * n.y, gf * n.z);
+      --i;
+      if (i >= 0) p_i = iterate(i);
     }
+    if (__any(G != 0.0f)) scene.vjp(anchor, G);       // parameter gradients of the whole run at once
+    if (walked) *walked += 2;
+    if (done) { finish_frozen(i); return lam; }
+  }
+  if (i < 0) return lam;
+#endif
+  // Rays that are still travelling (grazing a surface, threading a blend region) need a VJP at every one of
+  // their remaining steps, and a wave that walks them one after the other IS the critical path of the whole
+  // launch (config 4: 7 % of the wave tiles walked all 64 steps, with ~14 of their 64 lanes still active, while
+  // the rest of the GPU idled).  Such rays are handed to k_bwd_hard_n / _a / _b, which evaluate all their
+  // (ray, step) pairs in parallel; lanes whose adjoint component along the ray is already noise are finished.
+  if (early && i + 1 > RM_BWD_INLINE_STEPS) {
+    const float gf0 = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+    const bool active = !noise(gf0);
+    if (!__any(active)) { finish_frozen(i); return lam; }
+    const bool deferred = defer(i, lam, gv, active);
+    if (deferred) {
+      if (deferred_out) *deferred_out = true;
+      lam = mk3(0.0f, 0.0f, 0.0f);                 // contributes nothing below; its outputs come from k_bwd_hard_a
+    }
+    if (!__any(active && !deferred)) {               // nobody left to walk here
+      if (!deferred) finish_frozen(i);
+      return lam;
+    }
+  }
+  V3 p_next = iterate(i);
+  for (; i >= 0; --i) {
+    float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+    if (early && __all(noise(gf))) { finish_frozen(i); break; }
     V3 p = p_next;
-    if (i > 0) p_next = (i - 1 < nexec) ? load3(traj + 3 * (int64_t)(i - 1) * traj_stride, ray) : p_final;
+    if (i > 0) p_next = iterate(i - 1);
     float f;
     V3 gp = scene.vjp(p, gf, &f);
     if (want_gv) gv = gv + f * lam;
     lam = lam + gp;
+    if (walked) *walked += 1;
   }
   return lam;
 }
@@ -452,7 +522,16 @@ struct RenderArgs {
   float* partials;
   float* grad_pos;           // nullable [R,3]: dL/d(ray origin)   (feeds rm_camera_backward)
   float* grad_dirs;          // nullable [R,3]: dL/d(ray direction)
+  // deferred rays of the reverse sweep (k_bwd_hard_*), all nullable / 0
+  int32_t* hard_ray;         // [cap] band-output index of the ray
+  int32_t* hard_step;        // [cap] highest step index still to be walked
+  float* hard_state;         // [cap][8] lambda(3), dL/dv so far(3)
+  float* hard_n;             // [steps][cap][4] grad_p f(p_s) for unit upstream, f(p_s)
+  float* hard_g;             // [steps][cap] upstream g_s
+  int32_t hard_cap;
 };
+
+#define RM_WORK_HARD_COUNT 32      // workspace word (own 128-B line): rays deferred by k_render_bwd
 
 // Work decomposition of a frame: a *wave tile* is 64 rays handled by one wavefront --
 // an 8x8 pixel tile (RM_FLAG_TILE8X8, better convergence coherence for the wave-uniform
@@ -974,6 +1053,29 @@ __global__ void k_camera_bwd_finish(const float* __restrict__ partials, int bloc
   else if (gt) gt[3 * c + (k - 4)] = s;
 }
 
+// appends the active lanes of a wave to the deferred-ray list (one returning atomic per wave)
+struct DeferToList {
+  const RenderArgs& a;
+  int64_t li;
+  RM_DEV bool operator()(int i, V3 lam, V3 gv, bool active) const {
+    if (a.hard_cap <= 0 || !a.minmax) return false;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(active);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.minmax[RM_WORK_HARD_COUNT], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const bool ok = active && slot < (uint32_t)a.hard_cap;       // list full: the wave walks these rays itself
+    if (ok) {
+      a.hard_ray[slot] = (int32_t)li;
+      a.hard_step[slot] = i;
+      float* st = a.hard_state + 8 * (int64_t)slot;
+      st[0] = lam.x; st[1] = lam.y; st[2] = lam.z; st[3] = gv.x; st[4] = gv.y; st[5] = gv.z;
+    }
+    return ok;
+  }
+};
+
 // VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
 template <class Cfg>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
@@ -1013,10 +1115,152 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     }
     V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
     int ne = a.nexec ? a.nexec[li] : a.steps;
+    int walked;
+    bool deferred;
     lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
-                        a.flags & RM_FLAG_EARLY_OUT);
-    if (live && a.grad_pos) store3(a.grad_pos, li, lam);
-    if (live && a.grad_dirs) store3(a.grad_dirs, li, gv);
+                        a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
+    if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
+    if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam);
+    if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);
+  }
+  flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
+}
+
+// ---- deferred rays: every (ray, step) pair in parallel ------------------------------------------------------
+// The reverse recursion  lambda_s = lambda_{s+1} + g_s n_s,  g_s = lambda_{s+1}.v,  dL/dtheta += g_s df/dtheta(p_s)
+// is serial only in the three numbers lambda; n_s = grad_p f(p_s) and the parameter VJPs do not depend on it.
+//   k_bwd_hard_n : n_s (and f(p_s)) for every deferred ray and step        -- parallel over (ray, step)
+//   k_bwd_hard_a : the recursion itself, a dozen flops per step             -- parallel over rays
+//   k_bwd_hard_b : parameter gradients g_s df/dtheta(p_s)                    -- parallel over (ray, step)
+RM_DEV int hard_count(const RenderArgs& a) {
+  const uint32_t c = a.minmax[RM_WORK_HARD_COUNT];
+  return (int)(c < (uint32_t)a.hard_cap ? c : (uint32_t)a.hard_cap);
+}
+
+// wave items: 64 consecutive deferred rays at one step
+struct HardItem {
+  int s, h;
+  bool need;      // this lane has a ray and the step is one of its remaining ones
+  int64_t ray;
+};
+RM_DEV HardItem hard_item(const RenderArgs& a, int64_t item, int groups, int H) {
+  HardItem it;
+  it.s = (int)(item / groups);
+  it.h = (int)(item % groups) * 64 + (threadIdx.x & 63);
+  const int hc = it.h < H ? it.h : H - 1;
+  it.need = it.h < H && it.s <= a.hard_step[hc];
+  it.ray = a.hard_ray[hc];
+  return it;
+}
+RM_DEV V3 hard_point(const RenderArgs& a, int64_t R, int s, int64_t ray) {
+  const int ne = a.nexec ? a.nexec[ray] : a.steps;
+  return (s < ne) ? load3(a.traj + 3 * (int64_t)s * R, ray) : load3(a.p_final, ray);
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256) k_bwd_hard_n(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store, true);
+  const int H = hard_count(a);
+  if (H == 0) return;
+  const int64_t R = (int64_t)a.cam.num_cameras * (a.row_end - a.row_begin) * a.cam.width;
+  const int groups = (H + 63) >> 6;
+  const int64_t items = (int64_t)groups * a.steps;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // the next item's list entry and trajectory point (two dependent, scattered loads) are fetched before the
+  // current item's VJP, so their latency hides behind ~600 instructions
+  const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  HardItem cur{0, 0, false, 0};
+  V3 pc = mk3(0.0f, 0.0f, 0.0f);
+  if (first < items) { cur = hard_item(a, first, groups, H); pc = hard_point(a, R, cur.s, cur.ray); }
+  for (int64_t item = first; item < items; item += nwaves) {
+    HardItem nxt{0, 0, false, 0};
+    V3 pn = mk3(0.0f, 0.0f, 0.0f);
+    if (item + nwaves < items) { nxt = hard_item(a, item + nwaves, groups, H); pn = hard_point(a, R, nxt.s, nxt.ray); }
+    if (__any(cur.need)) {
+      float f;
+      const V3 n = scene.vjp_point(pc, 1.0f, &f);
+      if (cur.need) {
+        float* dst = a.hard_n + 4 * ((int64_t)cur.s * a.hard_cap + cur.h);
+        dst[0] = n.x; dst[1] = n.y; dst[2] = n.z; dst[3] = f;
+      }
+    }
+    cur = nxt; pc = pn;
+  }
+}
+
+__global__ void k_bwd_hard_a(RenderArgs a) {
+  const int H = hard_count(a);
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const int W = a.cam.width, Hh = a.cam.height, rows = a.row_end - a.row_begin;
+  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
+  const int64_t li = a.hard_ray[h];
+  const int cam = (int)(li / ((int64_t)rows * W));
+  const int64_t rem = li - (int64_t)cam * rows * W;
+  const int row = (int)(rem / W), col = (int)(rem - (int64_t)row * W);
+  const int64_t gi = ((int64_t)cam * Hh + (row + a.row_begin)) * W + col;
+  const Pose ps = load_pose(a.orientation, a.translation, cam);
+  const V3 v = qrot(load3(static_cast<const float*>(a.cam.ray_directions), gi), ps.w, ps.qv);
+  const float* st = a.hard_state + 8 * (int64_t)h;
+  V3 lam = mk3(st[0], st[1], st[2]), gv = mk3(st[3], st[4], st[5]);
+  const bool want_gv = a.grad_dirs != nullptr;
+  int s = a.hard_step[h];
+  bool frozen = false;
+  while (s >= 0 && !frozen) {
+    // the recursion is a chain of dependent flops, the n_s it consumes are not: fetch eight steps' worth at once
+    float4 nf[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      nf[k] = (s - k >= 0) ? *reinterpret_cast<const float4*>(a.hard_n + 4 * ((int64_t)(s - k) * a.hard_cap + h))
+                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (s < 0 || frozen) break;
+      const float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+      if (fabsf(gf) <= 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z))) { frozen = true; break; }   // noise
+      a.hard_g[(int64_t)s * a.hard_cap + h] = gf;
+      if (want_gv) gv = gv + nf[k].w * lam;
+      lam = lam + mk3(gf * nf[k].x, gf * nf[k].y, gf * nf[k].z);
+      --s;
+    }
+  }
+  if (want_gv && s >= 0) {     // steps 0..s with lambda frozen: sum_i f(p_i) = (p_{s+1} - p_0).v / |v|^2
+    const V3 dp = hard_point(a, R, s + 1, li) - load3(a.traj, li);
+    const float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
+    gv = gv + sumf * lam;
+  }
+  for (; s >= 0; --s) a.hard_g[(int64_t)s * a.hard_cap + h] = 0.0f;
+  if (a.grad_pos) store3(a.grad_pos, li, lam);
+  if (a.grad_dirs) store3(a.grad_dirs, li, gv);
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256) k_bwd_hard_b(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store, true);
+  const int n_acc = Cfg::n_acc(a.scene);
+  zero_accumulators<Cfg>(scene, n_acc);
+  const int H = hard_count(a);
+  const int64_t R = (int64_t)a.cam.num_cameras * (a.row_end - a.row_begin) * a.cam.width;
+  const int groups = (H + 63) >> 6;
+  const int64_t items = (int64_t)groups * a.steps;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  auto fetch = [&](int64_t item, float& g, V3& p) {
+    g = 0.0f; p = mk3(0.0f, 0.0f, 0.0f);
+    if (item >= items) return;
+    const HardItem it = hard_item(a, item, groups, H);
+    g = it.need ? a.hard_g[(int64_t)it.s * a.hard_cap + it.h] : 0.0f;
+    p = hard_point(a, R, it.s, it.ray);
+  };
+  float gc; V3 pc;
+  fetch(first, gc, pc);
+  for (int64_t item = first; item < items; item += nwaves) {
+    float gn; V3 pn;
+    fetch(item + nwaves, gn, pn);                       // before the VJP: its latency hides behind it
+    if (__any(gc != 0.0f)) scene.vjp(pc, gc);
+    gc = gn; pc = pn;
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }

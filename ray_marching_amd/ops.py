@@ -300,6 +300,8 @@ _FUSED_VJP_MODES = {0, 4}            # shader modes rm_render_backward different
 # measurement hook (bench.py): when set to a list, Render.run appends a (start, end) pair of timing events
 # recorded on the launch stream immediately around the k_render_fwd launch
 kernel_event_sink = None
+bwd_hard_capacity = None      # None: default sizing of the deferred-ray list of rm_render_backward; 0 = off (A/B probes)
+bwd_tile_cost_sink = None     # measurement hook (profiles/): int32 [wave tiles] tensor receiving rm_render_backward's tile_cost
 
 
 class Render(torch.autograd.Function):
@@ -414,10 +416,18 @@ class Render(torch.autograd.Function):
             need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             gpos = torch.empty_like(p_final) if need_pose else None
             gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
+            # deferred-ray workspace: room for one ray in eight (config 4 defers 2 %; the rest is walked in place)
+            hard_cap = 0 if (bwd_hard_capacity == 0 or ctx.steps == 0) else \
+                (bwd_hard_capacity or max(4096, p_final.numel() // 3 // 8))
+            hard = torch.empty(int(_lib.rm_bwd_hard_floats(hard_cap, ctx.steps)), dtype=torch.float32, device=dev) \
+                if hard_cap else None
+            if bwd_tile_cost_sink is not None:             # measurement runs: word 32 of `work` = rays deferred
+                globals()["bwd_last_work"], globals()["bwd_last_hard"] = work, (hard, hard_cap)
             _abi.check(cs.lib(True, ctx.precision).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
-                                               ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags, stream),
+                                               ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags,
+                                               _abi.ptr(bwd_tile_cost_sink), _abi.ptr(hard), hard_cap, stream),
                        "rm_render_backward", cs.lib(True, ctx.precision))
         gq = gt = None
         if need_pose:

@@ -701,11 +701,14 @@ def test_union_culling_changes_no_bit(case, monkeypatch):
     """CULL_MIN (bounding-sphere skip of min-union children) is an exact optimisation:
     the same scene compiled with RM_CULL=0 and with culling gives identical values, identical
     point gradients and identical parameter gradients, and identical frames."""
-    from ray_marching_amd import _abi
+    from ray_marching_amd import _abi, ops
     from ray_marching_amd.compiler import compiled_for
     from ray_marching_amd.scene.scene_registry import (make_closed_test_scene, make_many_primitive_scene,
                                                        make_test_scene2)
     monkeypatch.setenv("RM_SPECIALIZE", "off")          # same (interpreter) kernels on both sides
+    # bitwise comparison of parameter gradients: keep every ray in its own wave (the deferred-ray list is filled
+    # through an atomic counter, so its order -- and with it the grouping of partial sums -- varies run to run)
+    monkeypatch.setattr(ops, "bwd_hard_capacity", 0)
     gen = torch.Generator().manual_seed(77)
     pts = torch.cat([torch.rand(4096, 3, generator=gen) * 8 - 4,          # far from the objects: culls fire
                      torch.rand(4096, 3, generator=gen) * 2 - 1]).to(DEV)   # among them: they do not
@@ -1014,3 +1017,39 @@ def test_module_surface_edge_cases():
     assert len(list(shared.parameters())) == 3          # radius, translation, orientation (radius only once)
     assert abs(ball.radius.grad.item() - r.grad.item()) <= 1e-4 * max(1.0, abs(r.grad.item()))
     assert (shared.sdfs[1].translation.grad.cpu() - tr.grad).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("capacity", [None, 37])
+def test_deferred_rays_give_the_same_gradients(capacity, kernel_path):
+    """rm_render_backward hands rays whose march has not settled to the (ray, step)-parallel kernels
+    k_bwd_hard_n/_a/_b.  Scene-parameter and pose gradients equal the ones of the in-place walk (list switched
+    off) up to summation order -- with the default list, and with a list far too small (37 rays: most are
+    walked in place, the rest deferred; both paths in one launch)."""
+    from ray_marching_amd import ops
+    from ray_marching_amd.scene.scene_registry import make_closed_test_scene
+    h, w, steps = 96, 128, 64
+    q0 = torch.nn.functional.normalize(torch.tensor([[0.98, 0.05, -0.12, 0.03]]), dim=-1)
+    t0 = torch.tensor([[0.15, -0.1, -1.2]])
+    wimg = torch.rand(1, h, w, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = {}
+    try:
+        for cap in (0, capacity):
+            ops.bwd_hard_capacity = cap
+            scene = make_closed_test_scene()
+            loop = H.make_loop(scene, h, w)
+            _check_path(scene, kernel_path)
+            q, t = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+            ops.bwd_tile_cost_sink = torch.zeros(int(__import__("ray_marching_amd")._abi.lib.rm_wave_tiles(1, h, w, 2)),
+                                                 dtype=torch.int32, device=DEV)
+            (loop(q, t, 0, 1, steps) * wimg).mean().backward()
+            res[cap] = ([p.grad.clone() for p in scene.parameters()], q.grad.clone(), t.grad.clone(),
+                        ops.bwd_tile_cost_sink.clone())
+    finally:
+        ops.bwd_hard_capacity = None
+        ops.bwd_tile_cost_sink = None
+    a, b = res[0], res[capacity]
+    assert int(a[3].max()) > 8, "this frame is expected to contain rays that walk many steps"
+    if capacity is None:
+        assert int(b[3].max()) <= int(a[3].max()) // 2          # the long walks moved to the parallel kernels
+    for x, y in zip(a[0] + [a[1], a[2]], b[0] + [b[1], b[2]]):
+        assert (x - y).abs().max().item() <= 2e-6 * max(1.0, x.abs().max().item())
