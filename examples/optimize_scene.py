@@ -99,17 +99,10 @@ def run_graphed(size=512, march_steps=64, iters=200, lr=1e-3, device="cuda", log
 
     warm = 3
     losses = []
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warm):                      # warm-up iterations are real optimiser steps
-            opt.zero_grad(set_to_none=True)
-            losses.append(step().item())
-    torch.cuda.current_stream().wait_stream(side)
-    opt.zero_grad(set_to_none=True)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        loss = step()
+    from ray_marching_amd.graphs import capture_step
+    # warm-up iterations are real optimiser steps; warm-up and capture share one stream (ray_marching_amd/graphs.py)
+    graph, loss, _ = capture_step(lambda: losses.append(step()) or losses[-1], params, warmup=warm)
+    losses[:] = [x.item() for x in losses[:warm]]
     losses.append(float("nan"))                    # the capture pass itself does not execute
     torch.cuda.synchronize()
     t0 = time.perf_counter()

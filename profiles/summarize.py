@@ -69,7 +69,13 @@ if "SQ_INSTS_VALU" in k and "GRBM_GUI_ACTIVE" in k:
     k["valu_wave_instructions_per_simd_cycle"] = k["SQ_INSTS_VALU"] / 1024 / cycles
     k["valu_issue_utilisation"] = 2 * k["SQ_INSTS_VALU"] / 1024 / cycles   # wave64 on SIMD32 = 2 cycles/instr
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+sys.path.insert(0, root)
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("_rm_build", os.path.join(root, "ray_marching_amd", "_build.py"))
+_build = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_build)
 json.dump({"source": f"profiles/{tag}_pmc_summary.json",
+           # bench.py only quotes these numbers while the kernel sources are the ones they were measured on
+           "sources_hash": _build.sources_hash(),
            "k_render_fwd_hbm_bytes_per_launch": r_fetch + r_write,
            "k_render_fwd_valu_wave_instructions_per_launch": k.get("SQ_INSTS_VALU")},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -99,14 +99,17 @@ class RenderLoop(nn.Module):
     def __init__(self, scene, num_cameras: int = 1, px_width: int = 800, px_height: int = 800,
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
                  normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True,
-                 dynamic_tiles: bool = True, precision: str = "exact"):
+                 dynamic_tiles: bool = True, precision: str = "exact", rows=None):
+        """Arguments of the reference's RenderLoop (control.py:198-208) plus kernel options.  ``rows=(r0, r1)``:
+        this loop only ever renders that band of the frame (one rank of a row-tiled multi-GPU render) and keeps
+        only that band of the camera buffers; ``forward`` then returns [N, r1-r0, W, 3]."""
         super().__init__()
         self.scene = scene
         self.px_width = px_width
         self.px_height = px_height
         self.camera = PinholeCamera(num_cameras=num_cameras, px_width=px_width, px_height=px_height,
                                     focal_length=focal_length, sensor_width=sensor_width,
-                                    sensor_height=sensor_height)
+                                    sensor_height=sensor_height, rows=rows)
         self.marcher = SDFMarcher(sdf_scene=self.scene, early_out=early_out)
         self.normals = SDFNormals(sdf_scene=self.scene, normals_eps=normals_eps)
         self.shader = Shader()
@@ -172,6 +175,11 @@ class RenderLoop(nn.Module):
         1/2/5 (see ray_marching_amd/distributed.py); ``tile_order`` / ``tile_cost``: rm_render_forward's
         scheduling hint and per-tile cost output (include/rm_abi.h)."""
         mode = mode % 8
+        r0 = self.camera.rows[0]
+        if rows is not None and r0:          # a band loop: frame rows -> rows of its own buffers
+            if rows[0] < r0 or rows[1] > self.camera.rows[1]:
+                raise ValueError(f"rows {tuple(rows)} outside this loop's band {self.camera.rows}")
+            rows = (rows[0] - r0, rows[1] - r0)
         cs = compiled_for(self.scene)
         training = torch.is_grad_enabled() and (orientations.requires_grad or translations.requires_grad
                                                 or any(p.requires_grad for p in cs.leaves))

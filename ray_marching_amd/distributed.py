@@ -48,13 +48,29 @@ def row_band(height: int, rank: int, world: int) -> tuple[int, int]:
 
 
 class RowTileRenderer:
-    def __init__(self, loop=None, group=None, render_fn: Optional[Callable] = None, height: Optional[int] = None):
+    """``exchange``: how the tiles reach the gathering rank.
+      "p2p"    (default) one point-to-point transfer per peer, all posted together
+               (``dist.batch_isend_irecv``): on xGMI every peer has its own link to the root, so the 7 tiles
+               of an 8-GPU node arrive over 7 links at once instead of one ring;
+      "gather" ``dist.gather`` / ``dist.all_gather`` -- the collective the p2p path is checked against."""
+
+    def __init__(self, loop=None, group=None, render_fn: Optional[Callable] = None, height: Optional[int] = None,
+                 exchange: str = "p2p", width: Optional[int] = None, num_cameras: Optional[int] = None, device=None):
         if loop is None and render_fn is None:
             raise ValueError("need a RenderLoop or a render_fn")
+        if exchange not in ("p2p", "gather"):
+            raise ValueError("exchange must be 'p2p' or 'gather'")
         self.loop = loop
         self.group = group
+        self.exchange = exchange
         self.render_fn = render_fn if render_fn is not None else self._hip_band
         self.height = height if height is not None else loop.px_height
+        # shape / placement of an EMPTY tile (a surplus rank has nothing to render but still joins every exchange)
+        cam = getattr(loop, "camera", None)
+        self.width = width if width is not None else (loop.px_width if loop is not None else None)
+        self.num_cameras = num_cameras if num_cameras is not None else (cam.ray_positions.shape[0] if cam is not None else 1)
+        self.device = torch.device(device) if device is not None else (cam.ray_positions.device if cam is not None else torch.device("cpu"))
+        self.dtype = cam.ray_positions.dtype if cam is not None else torch.float32
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -85,6 +101,34 @@ class RowTileRenderer:
         return self.render_fn(orientations, translations, mode, degree, marching_steps, (r0, r1),
                               self._allreduce_minmax)
 
+    def _empty_tile(self, like):
+        if like is not None:
+            return like.new_zeros((like.shape[0], 0, like.shape[2], 3))
+        if self.width is None:
+            raise ValueError("a rank without rows needs the frame width (RowTileRenderer(width=...)) or `like`")
+        return torch.zeros((self.num_cameras, 0, self.width, 3), dtype=self.dtype, device=self.device)
+
+    def _exchange(self, padded: torch.Tensor, dst: Optional[int]):
+        """All tiles (list in rank order) on rank ``dst`` (None elsewhere), or on every rank for dst=None."""
+        if dst is None:
+            parts = [torch.empty_like(padded) for _ in range(self.world)]
+            dist.all_gather(parts, padded, group=self.group)
+            return parts
+        if self.exchange == "gather":
+            parts = [torch.empty_like(padded) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(padded, parts, dst=dst, group=self.group)
+            return parts
+        # point to point: the root posts one receive per peer, every peer one send, all in one batch
+        if self.rank == dst:
+            parts = [padded if r == dst else torch.empty_like(padded) for r in range(self.world)]
+            ops = [dist.P2POp(dist.irecv, parts[r], r, group=self.group) for r in range(self.world) if r != dst]
+        else:
+            parts = None
+            ops = [dist.P2POp(dist.isend, padded, dst, group=self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return parts
+
     def render(self, orientations, translations, mode: int = 0, degree: int = 1, marching_steps: int = 32,
                dst: Optional[int] = 0, like: Optional[torch.Tensor] = None):
         """Render this rank's band and gather the frame.  ``dst=None`` all-gathers (every rank gets
@@ -94,23 +138,18 @@ class RowTileRenderer:
             return tile
         per = -(-self.height // self.world)
         if tile is None:
-            # surplus rank still takes part in the collectives (incl. the min/max all-reduce)
+            # surplus rank: nothing to render, but it takes part in every exchange (incl. the min/max all-reduce);
+            # everything it needs is known BEFORE the first collective, so it cannot fail while the others wait
+            tile = self._empty_tile(like)
             if mode % 8 in (1, 2, 5):
-                lohi = torch.tensor([float("inf"), float("-inf")], device=like.device)
+                lohi = torch.tensor([float("inf"), float("-inf")], device=tile.device)
                 self._allreduce_minmax(lohi)
-            tile = like.new_zeros((like.shape[0], 0, like.shape[2], 3))
         tile = tile_payload(tile, mode)
         n, rows, w, c = tile.shape
         padded = tile if rows == per else torch.cat([tile, tile.new_zeros((n, per - rows, w, c))], dim=1)
-        padded = padded.contiguous()
-        if dst is None:
-            parts = [torch.empty_like(padded) for _ in range(self.world)]
-            dist.all_gather(parts, padded, group=self.group)
-        else:
-            parts = [torch.empty_like(padded) for _ in range(self.world)] if self.rank == dst else None
-            dist.gather(padded, parts, dst=dst, group=self.group)
-            if self.rank != dst:
-                return None
+        parts = self._exchange(padded.contiguous(), dst)
+        if parts is None:
+            return None
         frame = torch.cat(parts, dim=1)[:, : self.height]
         return expand_payload(frame)
 

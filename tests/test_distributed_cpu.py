@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from oracle import sdf_oracle as O
 
 PX, EPS = 3.45e-6, 5e-2
-H, W, STEPS = 22, 24, 24      # 22 rows: ragged over 3 ranks (8, 8, 6) and over 4 (6, 6, 6, 4)
+H, W, STEPS = 22, 24, 24      # 22 rows: ragged over 3 ranks (8, 8, 6); over 5 ranks (5, 5, 5, 5, 2)
 
 
 def _free_port():
@@ -45,7 +45,7 @@ def _oracle_band_renderer(spec, bufs, q_full, t_full):
     return render_fn
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, H=H):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,19 +55,46 @@ def _worker(rank, world, port, results):
         spec = O.scene_test2()
         bufs = O.camera_buffers(1, W, H, PX * H, PX * W, PX * H)
         q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -3.0]])
-        r = RowTileRenderer(render_fn=_oracle_band_renderer(spec, bufs, q, t), height=H)
+        r = RowTileRenderer(render_fn=_oracle_band_renderer(spec, bufs, q, t), height=H, width=W)   # exchange="p2p"
+        rg = RowTileRenderer(render_fn=_oracle_band_renderer(spec, bufs, q, t), height=H, width=W, exchange="gather")
         assert r.band() == row_band(H, rank, world)
-        like = torch.empty(1, 1, W, 3)
+
+        # RowTileRenderer(loop=...) drives the loop through RenderLoop.forward's own keyword contract
+        # (rows=, allreduce_minmax=): a stand-in loop with that signature, computing with the oracle
+        class FakeCamera:
+            ray_positions = bufs[0]
+            rows = (0, H)
+
+        class FakeLoop:
+            px_height, px_width, camera = H, W, FakeCamera()
+            band_fn = staticmethod(_oracle_band_renderer(spec, bufs, q, t))
+            calls = []
+
+            def __call__(self, orientations, translations, mode=0, degree=1, marching_steps=32, rows=None,
+                         allreduce_minmax=None):
+                self.calls.append((mode, rows, allreduce_minmax is not None))
+                return self.band_fn(orientations, translations, mode, degree, marching_steps, rows, allreduce_minmax)
+
+        fake = FakeLoop()
+        rl = RowTileRenderer(loop=fake)
         out = {}
         for mode in (0, 4, 1, 2, 5):
             with torch.no_grad():
-                frame = r.render(q, t, mode, 1, STEPS, dst=0, like=like)
-                every = r.render(q, t, mode, 1, STEPS, dst=None, like=like)
+                frame = r.render(q, t, mode, 1, STEPS, dst=0)            # no `like`: a surplus rank builds its own empty tile
+                checked = rg.render(q, t, mode, 1, STEPS, dst=0)
+                every = r.render(q, t, mode, 1, STEPS, dst=None)
+                via_loop = rl.render(q, t, mode, 1, STEPS, dst=0)
             assert (frame is not None) == (rank == 0)
             assert every.shape == (1, H, W, 3)
             if rank == 0:
                 assert torch.equal(frame, every)
+                assert torch.equal(frame, checked), "point-to-point exchange != dist.gather"
+                assert torch.equal(frame, via_loop)
                 out[mode] = frame
+        if r.band()[1] > r.band()[0]:
+            assert [c[0] for c in fake.calls] == [0, 4, 1, 2, 5] and all(c[1] == r.band() and c[2] for c in fake.calls)
+        else:
+            assert fake.calls == []
         # gradient all-reduce: each rank differentiates the loss of its own band
         gspec = O.map_spec(O.scene_test1_closed(), lambda x: x.clone().requires_grad_(True))
         r0, r1 = r.band()
@@ -91,14 +118,29 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, height=H):
     mgr = mp.Manager()
     results = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), results, height), nprocs=world, join=True)
     return dict(results)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+def test_surplus_rank_joins_every_exchange():
+    """4 rows over 3 ranks: bands of 2, 2 and 0 rows.  The rank without rows still takes part in the min/max
+    all-reduce and in both kinds of tile exchange (it used to dereference `like=None` while the other
+    ranks waited in the collective), and the frame equals the single-process one."""
+    got = _run(3, height=4)
+    spec = O.scene_test2()
+    bufs = O.camera_buffers(1, W, 4, PX * 4, PX * W, PX * 4)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -3.0]])
+    for mode, frame in got["frames"].items():
+        with torch.no_grad():
+            want = O.render(spec, bufs, q, t, mode, 1, STEPS, EPS)
+        assert frame.shape == (1, 4, W, 3)
+        torch.testing.assert_close(frame, want, rtol=0, atol=0 if mode in (0, 4) else 1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_row_tiles_match_single_process(world):
     got = _run(world)
     spec = O.scene_test2()
