@@ -158,7 +158,7 @@ int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
 
 int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps) {
   if (capacity <= 0 || steps < 0) return 0;
-  return capacity * (2 + 8) + (int64_t)steps * capacity * 5;      // ray, step, state[8]; n[steps][cap][4], g[steps][cap]
+  return capacity * (2 + 8) + (int64_t)steps * capacity * 6;      // ray, step, state[8]; n[steps][cap][4], g[steps][cap], pairs[steps*cap]
 }
 
 int rm_sdf_forward(const RmScene* scene, const void* points, void* dist, int64_t n, int32_t dtype, void* stream) {
@@ -457,7 +457,8 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   // deferred rays: only with the reverse early exit, a workspace for the list and its counter
   const bool defer = hard_ws && hard_capacity > 0 && work && (flags & RM_FLAG_EARLY_OUT) && steps > 0;
   if (defer) {
-    if (hard_capacity > (int64_t)1 << 30) return fail(RM_E_BADARG, "rm_render_backward: hard_capacity too large");
+    if (hard_capacity > (int64_t)1 << 21 || steps >= 2048)
+      return fail(RM_E_BADARG, "rm_render_backward: deferred-ray list limited to 2^21 rays and 2047 steps");
     const int64_t cap = hard_capacity;
     a.hard_cap = (int32_t)cap;
     a.hard_ray = reinterpret_cast<int32_t*>(hard_ws);
@@ -465,6 +466,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     a.hard_state = hard_ws + 2 * cap;
     a.hard_n = hard_ws + 10 * cap;
     a.hard_g = hard_ws + 10 * cap + (int64_t)steps * cap * 4;
+    a.hard_pairs = reinterpret_cast<uint32_t*>(hard_ws + 10 * cap + (int64_t)steps * cap * 5);
   }
   rm::k_render_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
@@ -475,7 +477,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     if (int e = pick_launch(rm::k_bwd_hard_b<GB>, *scene, true, 128, &LB)) return e;
     rm::k_bwd_hard_n<GB><<<2 * kMaxBlocksBwd, LN.block, LN.lds, (hipStream_t)stream>>>(a);   // no accumulators: 4 waves / SIMD
     if (int e = launched("k_bwd_hard_n")) return e;
-    rm::k_bwd_hard_a<<<(int)((hard_capacity + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+    rm::k_bwd_hard_a<<<(int)((hard_capacity + 63) / 64), 64, 0, (hipStream_t)stream>>>(a);   // one wave per block: more CUs busy
     if (int e = launched("k_bwd_hard_a")) return e;
     rm::RenderArgs b = a;
     b.partials = partials + (size_t)rows * (scene->n_params + scene->n_derived);     // its rows follow k_render_bwd's

@@ -323,9 +323,21 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       float m = -__builtin_inff();
       for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
       float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
-      float sum = aten_inner_sum(a1, [&](int i) { return rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm); });
-      const float L = rm_log(sum) + mm;
-      if (s.record) s.st->st(s.tape0 + a0 + a1, L);       // the reverse pass starts from it (slot after the children)
+      float L;
+      if (s.record) {
+        // forward half of a VJP: L only feeds softmax weights and sub-gradient choices of the reverse pass
+        // (contract 1e-4), so the hardware exponential / logarithm (~2 ulp) replace the two fp64 paths --
+        // ~110 fp64 instructions fewer per smooth union and VJP.  VALUES (march, distances, normals) never
+        // come through here: s.record is false for them.
+        float sum = 0.0f;
+        for (int i = 0; i < a1; ++i)
+          sum = sum + __builtin_amdgcn_exp2f((s.st->ld(s.tape0 + a0 + i) * nk - mm) * 1.44269504088896340736f);
+        L = __builtin_amdgcn_logf(sum) * 0.693147180559945309417f + mm;
+        s.st->st(s.tape0 + a0 + a1, L);                 // the reverse pass starts from it (slot after the children)
+      } else {
+        const float sum = aten_inner_sum(a1, [&](int i) { return rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm); });
+        L = rm_log(sum) + mm;
+      }
       s.d = L / nk;
     } break;
     case RM_OP_ROUND:

@@ -528,10 +528,13 @@ struct RenderArgs {
   float* hard_state;         // [cap][8] lambda(3), dL/dv so far(3)
   float* hard_n;             // [steps][cap][4] grad_p f(p_s) for unit upstream, f(p_s)
   float* hard_g;             // [steps][cap] upstream g_s
+  uint32_t* hard_pairs;      // [steps * cap] (ray slot << 11 | step) of every pair with g != 0, densely packed
   int32_t hard_cap;
 };
 
 #define RM_WORK_HARD_COUNT 32      // workspace word (own 128-B line): rays deferred by k_render_bwd
+#define RM_WORK_HARD_PAIRS 33      // workspace word: (ray, step) pairs listed by k_bwd_hard_a for k_bwd_hard_b
+#define RM_HARD_STEP_BITS 11       // steps < 2048, slots < 2^21 (checked on the host)
 
 // Work decomposition of a frame: a *wave tile* is 64 rays handled by one wavefront --
 // an 8x8 pixel tile (RM_FLAG_TILE8X8, better convergence coherence for the wave-uniform
@@ -1191,8 +1194,10 @@ __global__ void __launch_bounds__(256) k_bwd_hard_n(RenderArgs a) {
 
 __global__ void k_bwd_hard_a(RenderArgs a) {
   const int H = hard_count(a);
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= H) return;
+  const int h0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((h0 & ~63) >= H) return;                    // whole waves leave; the last wave keeps its idle lanes (ballots below)
+  const bool valid = h0 < H;
+  const int h = valid ? h0 : H - 1;
   const int W = a.cam.width, Hh = a.cam.height, rows = a.row_end - a.row_begin;
   const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
   const int64_t li = a.hard_ray[h];
@@ -1205,7 +1210,8 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
   const float* st = a.hard_state + 8 * (int64_t)h;
   V3 lam = mk3(st[0], st[1], st[2]), gv = mk3(st[3], st[4], st[5]);
   const bool want_gv = a.grad_dirs != nullptr;
-  int s = a.hard_step[h];
+  const int top = valid ? a.hard_step[h] : -1;
+  int s = top;
   bool frozen = false;
   while (s >= 0 && !frozen) {
     // the recursion is a chain of dependent flops, the n_s it consumes are not: fetch eight steps' worth at once
@@ -1225,14 +1231,30 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
       --s;
     }
   }
+  // The (ray, step) pairs k_bwd_hard_b has to visit are this ray's steps top .. s+1: listed densely, the space for
+  // a whole wave reserved with ONE returning atomic (a same-address atomic per step cost 12-16 ns each,
+  // chip-wide: 220 us for this kernel when it was tried).
+  {
+    const int lane = threadIdx.x & 63;
+    const uint32_t cnt = valid ? (uint32_t)(top - s) : 0u;
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(&a.minmax[RM_WORK_HARD_PAIRS], incl);
+    base = (uint32_t)__shfl((int)base, 63, 64) + (incl - cnt);
+    for (uint32_t k = 0; k < cnt; ++k)
+      a.hard_pairs[base + k] = ((uint32_t)h << RM_HARD_STEP_BITS) | (uint32_t)(top - (int)k);
+  }
   if (want_gv && s >= 0) {     // steps 0..s with lambda frozen: sum_i f(p_i) = (p_{s+1} - p_0).v / |v|^2
     const V3 dp = hard_point(a, R, s + 1, li) - load3(a.traj, li);
     const float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
     gv = gv + sumf * lam;
   }
-  for (; s >= 0; --s) a.hard_g[(int64_t)s * a.hard_cap + h] = 0.0f;
-  if (a.grad_pos) store3(a.grad_pos, li, lam);
-  if (a.grad_dirs) store3(a.grad_dirs, li, gv);
+  if (valid && a.grad_pos) store3(a.grad_pos, li, lam);
+  if (valid && a.grad_dirs) store3(a.grad_dirs, li, gv);
 }
 
 template <class Cfg>
@@ -1241,25 +1263,28 @@ __global__ void __launch_bounds__(256) k_bwd_hard_b(RenderArgs a) {
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(a.scene);
   zero_accumulators<Cfg>(scene, n_acc);
-  const int H = hard_count(a);
   const int64_t R = (int64_t)a.cam.num_cameras * (a.row_end - a.row_begin) * a.cam.width;
-  const int groups = (H + 63) >> 6;
-  const int64_t items = (int64_t)groups * a.steps;
+  // the (ray, step) pairs with a non-zero upstream, listed densely by k_bwd_hard_a: 64 of them per wave item,
+  // whatever ray and step they belong to (config 4: 10.8 k items instead of 17.6 k for ray-aligned items)
+  const int64_t npairs = a.minmax[RM_WORK_HARD_PAIRS];
+  const int64_t items = (npairs + 63) >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   auto fetch = [&](int64_t item, float& g, V3& p) {
     g = 0.0f; p = mk3(0.0f, 0.0f, 0.0f);
+    const int64_t k = item * 64 + (threadIdx.x & 63);
     if (item >= items) return;
-    const HardItem it = hard_item(a, item, groups, H);
-    g = it.need ? a.hard_g[(int64_t)it.s * a.hard_cap + it.h] : 0.0f;
-    p = hard_point(a, R, it.s, it.ray);
+    const uint32_t code = a.hard_pairs[k < npairs ? k : npairs - 1];
+    const int h = (int)(code >> RM_HARD_STEP_BITS), st = (int)(code & ((1u << RM_HARD_STEP_BITS) - 1u));
+    g = (k < npairs) ? a.hard_g[(int64_t)st * a.hard_cap + h] : 0.0f;
+    p = hard_point(a, R, st, a.hard_ray[h]);
   };
   float gc; V3 pc;
   fetch(first, gc, pc);
   for (int64_t item = first; item < items; item += nwaves) {
     float gn; V3 pn;
     fetch(item + nwaves, gn, pn);                       // before the VJP: its latency hides behind it
-    if (__any(gc != 0.0f)) scene.vjp(pc, gc);
+    scene.vjp(pc, gc);
     gc = gn; pc = pn;
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));

@@ -418,7 +418,7 @@ class Render(torch.autograd.Function):
             gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
             # deferred-ray workspace: room for one ray in eight (config 4 defers 2 %; the rest is walked in place)
             hard_cap = 0 if (bwd_hard_capacity == 0 or ctx.steps == 0) else \
-                (bwd_hard_capacity or max(4096, p_final.numel() // 3 // 8))
+                (bwd_hard_capacity or min(1 << 21, max(4096, p_final.numel() // 3 // 8)))
             hard = torch.empty(int(_lib.rm_bwd_hard_floats(hard_cap, ctx.steps)), dtype=torch.float32, device=dev) \
                 if hard_cap else None
             if bwd_tile_cost_sink is not None:             # measurement runs: word 32 of `work` = rays deferred
