@@ -136,7 +136,10 @@ enum {
 #define RM_WORK_QUEUES 64
 #define RM_WORK_QUEUE_STRIDE 32
 #define RM_WORK_QUEUE_BASE 64
-#define RM_WORK_WORDS (RM_WORK_QUEUE_BASE + RM_WORK_QUEUES * RM_WORK_QUEUE_STRIDE)
+#define RM_WORK_PARK_BASE (RM_WORK_QUEUE_BASE + RM_WORK_QUEUES * RM_WORK_QUEUE_STRIDE)
+#define RM_PARK_LISTS 8          /* one list of parked rays per check step (see rm_render_forward: park_ws) */
+#define RM_PARK_SHARDS 4         /* counters per list, each on its own 128-B line */
+#define RM_WORK_WORDS (RM_WORK_PARK_BASE + RM_PARK_LISTS * RM_PARK_SHARDS * 32)
 
 int rm_abi_version(void);
 const char* rm_last_error(void);
@@ -198,6 +201,13 @@ int rm_camera_forward(const RmCamera* cam, const void* orientation /*device [N,4
  *             sorted by decreasing cost (e.g. the previous frame's tile_cost) shortens the tail of the launch;
  *             any permutation gives the same image.
  *   tile_cost : nullable device int32[T] out: march steps the wave of each tile executed.
+ *   park_ws, park_capacity : nullable workspace of rm_park_floats(park_capacity) floats.  A wave leaves a tile when
+ *             ALL its 64 rays have settled into a bit-exact cycle; where only a minority is still moving (the
+ *             reference's default pose inside the torus: a third of the tiles run all 128 steps for 16 of their
+ *             64 rays on average), those rays are parked on a list at a check step and a second kernel
+ *             (k_render_parked) marches them on in dense waves and shades them.  Same pixels, bit for bit.
+ *             Requires RM_FLAG_EARLY_OUT, `minmax`, no trajectory recording, and a library built with
+ *             -DRM_PARKING (an opt-in: measured +12 % at that pose, -8 % on the headline frame); NULL / 0 = off.
  */
 int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                       const void* orientation, const void* translation,
@@ -205,7 +215,11 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
                       uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype,
                       int32_t mode, int32_t degree, int32_t steps,
                       int32_t row_begin, int32_t row_end, int32_t flags,
-                      const int32_t* tile_order, int32_t* tile_cost, void* stream);
+                      const int32_t* tile_order, int32_t* tile_cost,
+                      float* park_ws, int64_t park_capacity, void* stream);
+
+/* floats of a parking workspace for up to `capacity` rays (4 per ray: pixel index and the iterate) */
+int64_t rm_park_floats(int64_t capacity);
 
 /* number of wave tiles (64-ray work units) of a band of `rows` rows: length of tile_order / tile_cost */
 int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t flags);

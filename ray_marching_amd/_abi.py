@@ -34,7 +34,7 @@ _DTYPES = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.float64: DT
 def dtype_code(dtype) -> int:
     """RM_DTYPE_* of a torch dtype (KeyError for anything the kernels cannot read or write)."""
     return _DTYPES[dtype]
-WORK_WORDS = 64 + 64 * 32   # RM_WORK_WORDS
+WORK_WORDS = 64 + 64 * 32 + 8 * 4 * 32   # RM_WORK_WORDS (min/max words, tile queues, parking counters)
 CAMERA_BWD_BLOCKS = 256     # RM_CAMERA_BWD_BLOCKS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 
@@ -73,7 +73,8 @@ _SIGNATURES = {
     "rm_camera_forward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P]),
     "rm_render_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
                                     _P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    "rm_park_floats": (C.c_int64, [C.c_int64]),
     "rm_wave_tiles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),

@@ -291,7 +291,8 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
                       const void* translation, void* image, int32_t image_dtype, float* first_pass, float* p_final,
                       float* traj, int32_t* nexec, uint32_t* minmax, const void* cmap, int32_t cmap_size,
                       int32_t cmap_dtype, int32_t mode, int32_t degree, int32_t steps, int32_t row_begin,
-                      int32_t row_end, int32_t flags, const int32_t* tile_order, int32_t* tile_cost, void* stream) {
+                      int32_t row_end, int32_t flags, const int32_t* tile_order, int32_t* tile_cost,
+                      float* park_ws, int64_t park_capacity, void* stream) {
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
   if (!image) return fail(RM_E_BADARG, "rm_render_forward: null image");
   if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_render_forward: mode %d not in 0..7", mode);
@@ -312,6 +313,19 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype;
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
   a.tile_order = tile_order; a.tile_cost = tile_cost;
+  // ray parking (include/rm_abi.h): dense second kernel for the minority of rays that never settle
+  const int64_t park_seg = park_capacity / (RM_PARK_LISTS * RM_PARK_SHARDS);
+#ifdef RM_PARKING
+  const bool park = park_ws && park_seg >= 64 && park_seg < ((int64_t)1 << 30) && minmax && !traj &&
+                    (flags & RM_FLAG_EARLY_OUT) && steps >= 48;
+#else
+  const bool park = false;      // this library was built without -DRM_PARKING: the workspace is ignored
+#endif
+  if (park) {
+    a.park_seg = (int32_t)park_seg;
+    a.park_ray = reinterpret_cast<int32_t*>(park_ws);
+    a.park_p = park_ws + park_seg * RM_PARK_LISTS * RM_PARK_SHARDS;
+  }
   Launch L;
   if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
   const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
@@ -332,7 +346,21 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     if (grid > two_per_wave) grid = (int)(two_per_wave < 1 ? 1 : two_per_wave);
   }
   rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
-  return launched("k_render_fwd");
+  if (int e = launched("k_render_fwd")) return e;
+  if (park) {
+    Launch LP;
+    if (int e = pick_launch(rm::k_render_parked<G>, *scene, false, tune_block(), &LP)) return e;
+    int gp = 2 * cu_count();                       // 2 blocks per CU: dense items, ~100 steps each
+    rm::k_render_parked<G><<<gp, LP.block, LP.lds, (hipStream_t)stream>>>(a);
+    return launched("k_render_parked");
+  }
+  return RM_OK;
+}
+
+int64_t rm_park_floats(int64_t capacity) {
+  if (capacity <= 0) return 0;
+  const int64_t seg = capacity / (RM_PARK_LISTS * RM_PARK_SHARDS);
+  return seg * RM_PARK_LISTS * RM_PARK_SHARDS * 4;       // ray index + 3 floats per slot
 }
 
 int rm_minmax_init(uint32_t* minmax, void* stream) {

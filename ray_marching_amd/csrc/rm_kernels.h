@@ -195,9 +195,29 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 #define RM_EARLY_DENSE_STEPS 8    // look for cycles after every 2nd step up to here, after every 4th from then on
 #endif                            // (>= 4: the snapshot refreshes at steps 2 and 4 happen inside those looks)
 
-template <class SceneT>
+struct NoPark {
+  static constexpr bool kEnabled = false;
+  RM_DEV bool operator()(int, V3, bool) const { return false; }
+};
+
+#ifndef RM_PARK_MAX_LANES
+#define RM_PARK_MAX_LANES 40      // park only a minority: a tile whose rays are (nearly) all still moving stays put
+#endif
+#ifndef RM_PARK_FIRST
+#define RM_PARK_FIRST 2           // first check step, in strides (a ray parked early may have settled a few steps later)
+#endif
+
+// check steps of the parking lists: stride 16 for <= 128 steps, list k <-> step (k + 2) * stride
+RM_DEV int park_stride(int steps) { return steps <= 128 ? 16 : ((steps + 127) / 128) * 16; }
+
+// `park(step, p_next, unsettled)`: called wave-wide at a check step when 1..RM_PARK_MAX_LANES rays of the wave are
+// not yet in a proven cycle; returns (per lane) whether the ray was put on a list -- it then belongs to
+// k_render_parked and this wave neither waits for it nor stores its pixel (`parked` out).
+template <class SceneT, class ParkF = NoPark>
 RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* traj, int64_t traj_stride,
-                int64_t ray, bool live, int& nexec) {
+                int64_t ray, bool live, int& nexec, ParkF park = ParkF(), bool* parked = nullptr) {
+  if (parked) *parked = false;
+  const int pstride = park_stride(steps);
   V3 snap = p;          // remembered iterate p_s (per lane)
   int snap_step = 0;    // s            (wave-uniform: every lane refreshes at the same steps)
   int next_snap = 2;    // refresh the snapshot when the step index reaches this (2, 4, 8, ...)
@@ -225,6 +245,19 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
       const bool cyc = !traj && same_bits(pn, snap);
       const int found = fixed ? 1 : (cyc ? (i + 1 - snap_step) : 0);
       lambda = (lambda == 0) ? found : lambda;
+      if constexpr (ParkF::kEnabled) {
+        // a minority of the tile's rays still moving at a check step: hand them over instead of keeping 64 lanes
+        // (and the whole wave's issue slots) busy for them
+        const int done = i + 1;
+        if (!traj && done >= RM_PARK_FIRST * pstride && done < steps && done % pstride == 0) {
+          const bool unsettled = live && lambda == 0;
+          const int cnt = __popcll(__ballot(unsettled));
+          if (cnt > 0 && cnt <= RM_PARK_MAX_LANES) {
+            const bool gone = park(done, pn, unsettled);
+            if (gone) { *parked = true; lambda = 1; }          // no longer waited for; its pixel is not ours any more
+          }
+        }
+      }
       if (__all(lambda > 0)) {
         nexec = i + 1;
         int need = (steps - (i + 1)) % lambda;    // further steps this lane still has to take
@@ -522,6 +555,10 @@ struct RenderArgs {
   float* partials;
   float* grad_pos;           // nullable [R,3]: dL/d(ray origin)   (feeds rm_camera_backward)
   float* grad_dirs;          // nullable [R,3]: dL/d(ray direction)
+  // rays parked by the forward kernel for k_render_parked (nullable / 0)
+  int32_t* park_ray;         // [lists * shards][seg] band-output index
+  float* park_p;             // [lists * shards][seg][3] iterate after the check step
+  int32_t park_seg;          // rays per (list, shard) segment
   // deferred rays of the reverse sweep (k_bwd_hard_*), all nullable / 0
   int32_t* hard_ray;         // [cap] band-output index of the ray
   int32_t* hard_step;        // [cap] highest step index still to be walked
@@ -889,6 +926,38 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   }
 }
 
+// puts the unsettled lanes of a wave on the list of this check step (one returning atomic per wave, on one of
+// RM_PARK_SHARDS counters of the list)
+struct ParkToList {
+#ifdef RM_PARKING
+  static constexpr bool kEnabled = true;
+#else
+  static constexpr bool kEnabled = false;    // opt-in build (-DRM_PARKING): measured +12 % at the reference's pose (0,0,1),
+#endif                                       // -8 % at (0,0,-3) and -12 % on the 512^2 config-4 frame
+  const RenderArgs& a;
+  int64_t li;
+  RM_DEV bool operator()(int step, V3 p, bool unsettled) const {
+    if (!a.park_ray) return false;
+    const int k = step / park_stride(a.steps) - 2;
+    if (k < 0 || k >= RM_PARK_LISTS) return false;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int seg = k * RM_PARK_SHARDS + (int)(wave & (RM_PARK_SHARDS - 1));
+    const unsigned long long m = __ballot(unsettled);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.minmax[RM_WORK_PARK_BASE + 32 * seg], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const bool ok = unsettled && slot < (uint32_t)a.park_seg;     // segment full: the ray stays with its wave
+    if (ok) {
+      const int64_t at = (int64_t)seg * a.park_seg + slot;
+      a.park_ray[at] = (int32_t)li;
+      store3(a.park_p, at, p);
+    }
+    return ok;
+  }
+};
+
 template <class Cfg>
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   typename Cfg::Store store;
@@ -904,9 +973,56 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     const int64_t tile = a.tile_order ? (int64_t)a.tile_order[tc.tile] : tc.tile;
     TileRays r = load_tile_rays(a, tile);
     int nexec;
-    V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec);
+    bool parked;
+    V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec, ParkToList{a, r.li}, &parked);
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tile] = nexec;     // nexec is wave-uniform
+    r.live = r.live && !parked;                 // a parked ray's pixel is written by k_render_parked
     finish_tile(a, scene, T, r, p, nexec, mm);
+  }
+  if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
+    fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
+}
+
+// The rays parked by k_render_fwd, 64 of one list per wave: march the remaining steps (same deterministic
+// iteration, its own cycle detection from there on), then distance / normals / shader / store like any other ray.
+template <class Cfg>
+__global__ void __launch_bounds__(256) k_render_parked(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  Tetra T = load_tetra(a.tetra);
+  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
+  const bool early = a.flags & RM_FLAG_EARLY_OUT;
+  MinMaxAcc mm{__builtin_inff(), -__builtin_inff(), false};
+  const int pstride = park_stride(a.steps);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // next wave item of this wave
+  int64_t before = 0;                                                               // items of the segments already passed
+  for (int seg = 0; seg < RM_PARK_LISTS * RM_PARK_SHARDS; ++seg) {
+    const uint32_t c = a.minmax[RM_WORK_PARK_BASE + 32 * seg];
+    const int count = (int)(c < (uint32_t)a.park_seg ? c : (uint32_t)a.park_seg);
+    const int64_t n_items = (count + 63) >> 6;
+    const int done = (seg / RM_PARK_SHARDS + 2) * pstride;                          // steps these rays have behind them
+    for (; item < before + n_items; item += nwaves) {
+      const int idx = (int)(item - before) * 64 + (threadIdx.x & 63);
+      const bool live = idx < count;
+      const int64_t at = (int64_t)seg * a.park_seg + (live ? idx : count - 1);
+      TileRays r;
+      r.live = live;
+      r.li = a.park_ray[at];
+      const int cam = (int)(r.li / ((int64_t)rows * W));
+      const int64_t rem = r.li - (int64_t)cam * rows * W;
+      const int row = (int)(rem / W), col = (int)(rem - (int64_t)row * W);
+      const int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;
+      V3 o, v;
+      if (a.cam.dtype == RM_DTYPE_F16) load_ray_and_pose<_Float16>(a, gi, cam, o, v, r.ps);
+      else load_ray_and_pose<float>(a, gi, cam, o, v, r.ps);
+      r.o = qrot(o, r.ps.w, r.ps.qv) + r.ps.t;
+      r.v = qrot(v, r.ps.w, r.ps.qv);
+      int nexec;
+      V3 p = march(scene, load3(a.park_p, at), r.v, a.steps - done, early, nullptr, 0, r.li, live, nexec);
+      finish_tile(a, scene, T, r, p, done + nexec, mm);
+    }
+    before += n_items;
   }
   if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
     fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);

@@ -7,6 +7,8 @@ on a HIP device: there is deliberately no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _abi
@@ -300,6 +302,9 @@ _FUSED_VJP_MODES = {0, 4}            # shader modes rm_render_backward different
 # measurement hook (bench.py): when set to a list, Render.run appends a (start, end) pair of timing events
 # recorded on the launch stream immediately around the k_render_fwd launch
 kernel_event_sink = None
+# forward: park never-settling rays for a dense second kernel.  Needs libraries built with -DRM_PARKING
+# (RM_HIPCC_EXTRA="-DRM_PARKING" RM_PARK=1); off by default: +12 % at the reference's pose, slower everywhere else
+park_rays = os.environ.get("RM_PARK", "0") == "1"
 bwd_hard_capacity = None      # None: default sizing of the deferred-ray list of rm_render_backward; 0 = off (A/B probes)
 bwd_tile_cost_sink = None     # measurement hook (profiles/): int32 [wave tiles] tensor receiving rm_render_backward's tile_cost
 
@@ -358,6 +363,12 @@ class Render(torch.autograd.Function):
         traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
         nexec = torch.empty(R, dtype=torch.int32, device=dev) if record else None
         minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)   # global min/max words + dynamic tile counter
+        # parking workspace (rays that never settle are finished by a dense second kernel): room for 2 R rays
+        # over the 32 list segments; inference frames of >= 48 steps with the early-out only
+        park_cap = 0
+        if park_rays and not record and steps >= 48 and (flags & _abi.FLAG_EARLY_OUT) and R >= 4096:
+            park_cap = 2 * R
+        park = torch.empty(int(_lib.rm_park_floats(park_cap)), dtype=torch.float32, device=dev) if park_cap else None
         with torch.cuda.device(dev):
             stream = _abi.current_stream(dev)
             s, keep = cs.scene_struct(prm, dev)
@@ -374,7 +385,7 @@ class Render(torch.autograd.Function):
                                              _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                              0 if cmap is None else _abi.dtype_code(cmap.dtype),
                                              mode, degree, steps, r0, r1, flags, _abi.ptr(tile_order), _abi.ptr(tile_cost),
-                                             stream), "rm_render_forward", lib)
+                                             _abi.ptr(park), park_cap, stream), "rm_render_forward", lib)
             if sink is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()

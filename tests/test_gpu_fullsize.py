@@ -196,3 +196,38 @@ def test_main_py_loop_through_pose_player_and_frame_sink(tmp_path):
     window.close()
     assert window.frames == 7 and seen == set(range(8)) - {3}
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".ppm")) == [f"frame_{i:05d}.ppm" for i in range(7)]
+
+
+def test_parking_build_changes_no_pixel(tmp_path):
+    """The opt-in -DRM_PARKING build (rays that never settle are handed to a dense second kernel, k_render_parked)
+    renders the reference's default pose -- a third of the wave tiles park some of their rays there -- bit for bit
+    like the full-length march.  Runs in a child process: the variant libraries are built there (hipcc, ~30 s)."""
+    import subprocess
+    import sys
+    from ray_marching_amd import specialize
+    if specialize._hipcc() is None or not os.path.exists(specialize._hipcc()):
+        pytest.skip("hipcc not available on this box")
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from tests import helpers as H
+from oracle import sdf_oracle as O
+from ray_marching_amd import _abi
+h, w, steps = 1080, 1920, 128
+q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device="cuda")
+out = {}
+for z in (1.0, -3.0):
+    t = torch.tensor([[0.0, 0.0, z]], device="cuda")
+    for mode in (4, 1):
+        with torch.no_grad():
+            a = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)(q, t, mode, 1, steps)
+            b = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, early_out=False)(q, t, mode, 1, steps)   # no early-out: no parking
+        assert torch.equal(a, b), (z, mode)
+print("PARKING-OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RM_HIPCC_EXTRA="-DRM_PARKING", RM_PARK="1", RM_SPECIALIZE="jit")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    # the child rebuilt ray_marching_amd/lib/librm_hip.so with the extra flag: put the default build back
+    import __graft_entry__ as entry
+    entry.build_library(force=True)
+    assert r.returncode == 0 and "PARKING-OK" in r.stdout, r.stderr[-2000:]

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.rm_abi_version() == _abi.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "rm_abi.h")).read()
     assert f"#define RM_ABI_VERSION {_abi.ABI_VERSION}" in header
-    assert f"#define RM_WORK_WORDS" in header and _abi.WORK_WORDS == 64 + 64 * 32
+    assert f"#define RM_WORK_WORDS" in header and _abi.WORK_WORDS == 64 + 64 * 32 + 8 * 4 * 32
 
 
 def test_bad_arguments_return_error_codes_without_launching():
@@ -60,7 +60,7 @@ def test_bad_arguments_return_error_codes_without_launching():
 
     def render(mode, r0=0, r1=4, image_dtype=0, cam_=cam, cmap=None, cmap_dtype=0):
         return lib.rm_render_forward(ok, cam_, tet, 16, 16, 16, image_dtype, None, None, None, None, None, cmap,
-                                     0 if cmap is None else 8, cmap_dtype, mode, 1, 8, r0, r1, 0, None, None, None)
+                                     0 if cmap is None else 8, cmap_dtype, mode, 1, 8, r0, r1, 0, None, None, None, 0, None)
 
     assert render(9) == -1 and b"mode" in lib.rm_last_error()
     assert render(0, 2, 9) == -1                                          # band outside the frame
