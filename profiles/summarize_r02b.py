@@ -1,0 +1,30 @@
+"""gpurun_out/prof_r02b (profiles/collect_r02.sh) -> profiles/r02_bwd_kernel_stats.csv, r02_bwd_pmc_summary.json,
+r02_fp16_frame_kernel_stats.csv"""
+import csv, glob, json, os, shutil
+from collections import defaultdict
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_r02b")
+out = os.path.join(root, "profiles")
+shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_bwd_kernel_stats.csv"))
+shutil.copy(glob.glob(os.path.join(src, "fp16", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_fp16_frame_kernel_stats.csv"))
+# FETCH_SIZE correction measured in the same round on k_camera_fwd (profiles/r02_pmc_summary.json)
+corr = json.load(open(os.path.join(out, "r02_pmc_summary.json")))
+ff, wf = corr["FETCH_SIZE_correction"], corr["WRITE_SIZE_correction"]
+res = defaultdict(dict)
+for sub, name, f in (("pmc_fetch", "FETCH_SIZE", ff), ("pmc_write", "WRITE_SIZE", wf)):
+    acc = defaultdict(list)
+    for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == name:
+                acc[r["Kernel_Name"].split("<")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if k.startswith("rm::"):
+            res[k][name + "_bytes_per_launch"] = sum(v) / len(v) * 1024 * f
+for k in res:
+    res[k]["hbm_bytes_per_launch"] = sum(res[k].values())
+rays, S = 512 * 512, 64
+summary = {"config": "closed make_test_scene 512x512x64 training step (profiles/bwd_probe.py)",
+           "FETCH_SIZE_correction": ff, "WRITE_SIZE_correction": wf, "kernels": res,
+           "algorithmic": {"k_render_fwd (recording)": rays * (24 + 12 + 12 + 12 * S), "backward kernels": rays * 12 * (S + 3)}}
+json.dump(summary, open(os.path.join(out, "r02_bwd_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))

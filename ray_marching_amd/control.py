@@ -185,13 +185,19 @@ class RenderLoop(nn.Module):
                                                 or any(p.requires_grad for p in cs.leaves))
         rp, rd = self._io_buffers(training)
         cmap = self._cmap(rp.device) if mode in (6, 7) else None
-        # training frames pack the parameters with torch.cat (the autograd edge back to every nn.Parameter);
-        # inference frames let the kernel gather them from the parameter storages (nothing to go stale)
-        params = cs.pack_params(rp.device) if (training or _AB_PACK) else None
+        # The kernels gather the parameter block from the nn.Parameter storages themselves (nothing to pack,
+        # nothing to go stale); a training frame hands the Parameters to the autograd Function as its leaves.
+        # Only parameters that cannot be read in place (other device / dtype) are packed with torch.cat.
+        params, leaves = None, ()
+        if training or _AB_PACK:
+            if _AB_PACK or cs.param_table(rp.device) is None:
+                params = cs.pack_params(rp.device)
+            else:
+                leaves = cs.leaves
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
-                                 self.precision, None, tile_order, tile_cost)
+                                 self.precision, None, tile_order, tile_cost, leaves)
         out_dtype = self.camera.ray_positions.dtype
         if mode in (6, 7):
             out_dtype = torch.promote_types(out_dtype, self.shader.cyclic_cmap.dtype)

@@ -297,6 +297,7 @@ def camera_forward(ray_positions, ray_directions, orientation, translation):
 # --------------------------------------------------------------------------
 _GLOBAL_MODES = (1, 2, 5)
 _FUSED_VJP_MODES = {0, 4}            # shader modes rm_render_backward differentiates through
+_N_FIXED_ARGS = 18                   # Render.forward arguments in front of *leaves
 
 
 # measurement hook (bench.py): when set to a list, Render.run appends a (start, end) pair of timing events
@@ -322,22 +323,26 @@ class Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions,
                 tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
-                precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None):
+                precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None, *leaves):
+        """``params``: the packed block (a differentiable torch.cat of the leaves), or None with the scene's
+        nn.Parameters themselves as trailing ``leaves``: the kernels then gather the block from the parameter
+        storages (CompiledScene.param_table) -- no pack kernel, and autograd sees ONE node in front of the
+        leaves instead of a cat + 2 view nodes per leaf (0.1 ms of host time per config-4 step)."""
         return Render.run(ctx, ctx.needs_input_grad, params, orientation, translation, cs, ray_positions,
                           ray_directions, tetra, cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision,
-                          image_dtype, tile_order, tile_cost)
+                          image_dtype, tile_order, tile_cost, leaves)
 
     @staticmethod
     def run(ctx, needs_input_grad, params, orientation, translation, cs: CompiledScene, ray_positions,
             ray_directions, tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
-            precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None):
+            precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None, leaves=()):
         """Body of the forward pass.  ``ctx`` is None for inference frames, which skip the autograd
         machinery altogether (render_frame below)."""
         _require_device(ray_positions, "camera buffers")
         _require_device(orientation, "orientations")
         dev = ray_positions.device
         prm = None if params is None else _f32c(params)       # None: the kernel gathers from the parameter storages
-        need_grad = any(needs_input_grad[:3])
+        need_grad = any(needs_input_grad[:3]) or any(needs_input_grad[_N_FIXED_ARGS:])
         have_vjp = mode in _FUSED_VJP_MODES
         record = need_grad and have_vjp
         if record and (ray_positions.dtype != torch.float32 or ray_directions.dtype != torch.float32):
@@ -402,7 +407,9 @@ class Render(torch.autograd.Function):
             ctx.have_vjp = have_vjp
             ctx.mode = mode
         if record:
-            ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec)
+            # the leaves are saved too: autograd then refuses a backward after an in-place edit of a parameter
+            # (the backward kernels read the live storages, which must still hold the forward's values)
+            ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
             ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
             ctx.precision = precision
         return image
@@ -413,7 +420,7 @@ class Render(torch.autograd.Function):
             # the frame itself rendered (like the reference, which renders every mode with grad enabled);
             # only differentiating through a shader without a fused VJP is refused
             raise NotImplementedError(f"fused backward exists for shader modes {sorted(_FUSED_VJP_MODES)}, not {ctx.mode}")
-        prm, q, t, rp, rd, p_final, traj, nexec = ctx.saved_tensors
+        prm, q, t, rp, rd, p_final, traj, nexec, *leaves = ctx.saved_tensors
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
@@ -443,22 +450,28 @@ class Render(torch.autograd.Function):
         gq = gt = None
         if need_pose:
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        gp_out = gprm[: prm.numel()] if ctx.needs_input_grad[0] else None
-        return (gp_out, gq, gt) + (None,) * 15
+        gp_out = gprm[: prm.numel()] if (prm is not None and ctx.needs_input_grad[0]) else None
+        leaf_grads, o = [], 0
+        for k, p in enumerate(leaves):          # named_parameters() order = block order
+            n = p.numel()
+            leaf_grads.append(gprm[o:o + n].view(p.shape).to(p.dtype) if ctx.needs_input_grad[_N_FIXED_ARGS + k] else None)
+            o += n
+        return (gp_out, gq, gt) + (None,) * (_N_FIXED_ARGS - 3) + tuple(leaf_grads)
 
 
-_NO_GRAD = (False, False, False)
+_NO_GRAD = (False,) * 3
 
 
 def render_frame(params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions, tetra, cmap,
                  mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax, precision: str = "exact",
-                 image_dtype=None, tile_order=None, tile_cost=None):
+                 image_dtype=None, tile_order=None, tile_cost=None, leaves=()):
     """One frame.  Goes through autograd only when something can receive a gradient; an inference frame
     calls the launch code directly (autograd.Function.apply costs ~20 us per call even under no_grad)."""
     if torch.is_grad_enabled() and ((params is not None and params.requires_grad) or orientation.requires_grad
-                                    or translation.requires_grad):
+                                    or translation.requires_grad or any(p.requires_grad for p in leaves)):
         return Render.apply(params, orientation, translation, cs, ray_positions, ray_directions, tetra, cmap, mode,
-                            degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order, tile_cost)
+                            degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order, tile_cost,
+                            *leaves)
     return Render.run(None, _NO_GRAD, params, orientation, translation, cs, ray_positions, ray_directions, tetra,
                       cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order,
                       tile_cost)
