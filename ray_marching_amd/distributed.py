@@ -79,12 +79,19 @@ class RowTileRenderer:
         return self.loop(orientations, translations, mode, degree, steps, rows=rows,
                          allreduce_minmax=allreduce_minmax)
 
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """gloo moves host memory: device tensors are staged through the host for it (rehearsals of the N > 1
+        path on a box without RCCL peers; with backend "nccl" = RCCL the device buffers go over xGMI directly)."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     # -- global min/max of the normalised shaders -------------------------------------------
     def _allreduce_minmax(self, lohi: torch.Tensor):
         """lohi = [min, max] of this rank's band, reduced in place over the group."""
         if self.world == 1:
             return
-        lo, hi = lohi[:1].clone(), lohi[1:].clone()
+        staged = self._host_staged(lohi)
+        src = lohi.cpu() if staged else lohi
+        lo, hi = src[:1].clone(), src[1:].clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         lohi[0:1].copy_(lo)
@@ -110,6 +117,10 @@ class RowTileRenderer:
 
     def _exchange(self, padded: torch.Tensor, dst: Optional[int]):
         """All tiles (list in rank order) on rank ``dst`` (None elsewhere), or on every rank for dst=None."""
+        if self._host_staged(padded):
+            device = padded.device
+            parts = self._exchange(padded.cpu(), dst)
+            return None if parts is None else [p.to(device) for p in parts]
         if dst is None:
             parts = [torch.empty_like(padded) for _ in range(self.world)]
             dist.all_gather(parts, padded, group=self.group)

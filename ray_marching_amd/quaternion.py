@@ -18,12 +18,18 @@ def cross_product(U: Tensor, V: Tensor) -> Tensor:
 
 
 def multiply(p: Tensor, q: Tensor) -> Tensor:
-    """Hamilton product p (x) q."""
-    pw, pv = p[..., :1], p[..., 1:]
-    qw, qv = q[..., :1], q[..., 1:]
-    w = pw * qw - (pv * qv).sum(-1, keepdim=True)
-    v = pw * qv + qw * pv + cross_product(pv, qv)
-    return torch.cat((w, v), dim=-1)
+    """Hamilton product p (x) q, with the operand and summation order of the reference (quaternion.py:38-46):
+    each component is a three-term sum (rounded left to right) minus or plus one product."""
+    p0, p1, p2, p3 = p.unbind(-1)
+    q0, q1, q2, q3 = q.unbind(-1)
+
+    def s3(a, b, c):
+        return torch.stack((a, b, c), dim=-1).sum(-1)
+
+    return torch.stack((p0 * q0 - s3(p1 * q1, p2 * q2, p3 * q3),
+                        s3(p0 * q1, p1 * q0, p2 * q3) - p3 * q2,
+                        s3(p0 * q2, p2 * q0, p3 * q1) - p1 * q3,
+                        s3(p0 * q3, p1 * q2, p3 * q0) - p2 * q1), dim=-1)
 
 
 def conjugate(q: Tensor) -> Tensor:

@@ -39,6 +39,10 @@ def load_cyclic_cmap() -> Tensor:
     path = Path("./data/cyclic_cmap.pt")
     if path.is_file():
         return torch.load(path, weights_only=True)
+    import warnings
+    warnings.warn("ray_marching_amd: ./data/cyclic_cmap.pt (the reference's colormap, loaded relative to the working "
+                  "directory at shader.py:177) is not here; the tangent / spin shaders will use a procedural cyclic "
+                  "colormap with different colours.  Assign Shader.cyclic_cmap to use another table.", stacklevel=3)
     return default_cyclic_cmap()
 
 

@@ -231,3 +231,71 @@ print("PARKING-OK")
     import __graft_entry__ as entry
     entry.build_library(force=True)
     assert r.returncode == 0 and "PARKING-OK" in r.stdout, r.stderr[-2000:]
+
+
+def _hip_band_worker(rank, world, port, h, w, steps, out_dir):
+    """One rank of a row-tiled render with the real HIP band renderer (both ranks share the box's one GPU; gloo
+    carries the collectives, device tensors staged through the host)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ray_marching_amd.control import RenderLoop
+        from ray_marching_amd.distributed import RowTileRenderer, all_reduce_gradients, row_band
+        from ray_marching_amd.scene.scene_registry import make_closed_test_scene, make_test_scene2
+        torch.cuda.set_device(0)
+        band = row_band(h, rank, world)
+        loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=w, px_height=h, focal_length=H.PX * h,
+                          sensor_width=H.PX * w, sensor_height=H.PX * h, normals_eps=H.EPS, rows=band).to(DEV)
+        assert loop.camera.ray_positions.shape[1] == band[1] - band[0]          # only this rank's band is resident
+        q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV)
+        frames = {}
+        for exchange in ("p2p", "gather"):
+            tiles = RowTileRenderer(loop, exchange=exchange)
+            for mode in (4, 0, 1, 5):
+                with torch.no_grad():
+                    frame = tiles.render(q, t, mode, 1, steps, dst=0)
+                assert (frame is not None) == (rank == 0)
+                if rank == 0:
+                    frames[(exchange, mode)] = frame.cpu()
+        # training: each rank back-propagates the loss of its own band, gradients summed over the ranks
+        scene = make_closed_test_scene()
+        tl = RenderLoop(scene, num_cameras=1, px_width=w, px_height=h, focal_length=H.PX * h, sensor_width=H.PX * w,
+                        sensor_height=H.PX * h, normals_eps=H.EPS, rows=band).to(DEV)
+        tl(q, torch.tensor([[0.0, 0.0, -1.0]], device=DEV), 0, 1, 24).pow(2).sum().backward()
+        cpu_holder = torch.nn.ParameterList([torch.nn.Parameter(p.detach().cpu()) for p in scene.parameters()])
+        for hp, p in zip(cpu_holder, scene.parameters()):      # gloo: reduce on the host
+            hp.grad = p.grad.cpu()
+        all_reduce_gradients(cpu_holder)
+        if rank == 0:
+            torch.save({"frames": frames, "grads": [p.grad for p in cpu_holder]}, os.path.join(out_dir, "rank0.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_band_renderer_under_a_real_process_group(tmp_path):
+    """RowTileRenderer with the HIP RenderLoop as band renderer, two processes in one torch.distributed group
+    (gloo; both on this box's single GPU): frames equal the single-process render bit for bit -- per-pixel shaders
+    and, after the min/max all-reduce, the globally normalised ones; the point-to-point exchange equals
+    dist.gather; summed band gradients equal the whole-frame gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    from ray_marching_amd.scene.scene_registry import make_closed_test_scene
+    h, w, steps, world = 90, 160, 48, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hip_band_worker, args=(world, port, h, w, steps, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)      # written by this test
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV)
+    for (exchange, mode), frame in got["frames"].items():
+        with torch.no_grad():
+            want = loop(q, t, mode, 1, steps).cpu()
+        assert torch.equal(frame, want), (exchange, mode)
+    scene = make_closed_test_scene()
+    whole = H.make_loop(scene, h, w)
+    whole(q, torch.tensor([[0.0, 0.0, -1.0]], device=DEV), 0, 1, 24).pow(2).sum().backward()
+    for g, p in zip(got["grads"], scene.parameters()):
+        assert (g - p.grad.cpu()).abs().max().item() <= 2e-5 * max(1.0, p.grad.abs().max().item())

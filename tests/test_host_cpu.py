@@ -298,7 +298,7 @@ def test_quaternion_helpers_match_oracle():
     assert torch.equal(Q.cross_product(u, v), O.cross(u, v))
     assert torch.equal(Q.rotation(u, q), O.quat_rotate(u, q))
     assert torch.equal(Q.conjugate(q), O.quat_conj(q))
-    torch.testing.assert_close(Q.multiply(p, q), O.quat_multiply(p, q), rtol=1e-6, atol=1e-6)
+    assert torch.equal(Q.multiply(p, q), O.quat_multiply(p, q))      # the reference's op order (quaternion.py:38-46), bit for bit
     torch.testing.assert_close(Q.QuaternionToSO3()(q), O.quat_to_so3(q), rtol=1e-6, atol=1e-6)
     w = Q.to_versor(torch.tensor([[0.1, 0.2, 0.2]]))
     assert w.shape == (1, 4) and w.norm().item() == pytest.approx(1.0, abs=1e-6)
