@@ -252,7 +252,10 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
                       float* grad_dirs, float* grad_normals, int32_t mode, int64_t n_pixels,
                       int64_t pixels_per_camera, void* stream);
 
-/* VJP of rm_render_forward w.r.t. scene parameters (modes 0 and 4; others return RM_E_BADARG).
+/* VJP of rm_render_forward w.r.t. scene parameters and, through the per-ray outputs, the camera pose.  Shader modes
+ * with a fused VJP: 0 lambertian, 3 vignette, 4 normal, 6 tangent, 7 spin (the colormap index is piecewise constant;
+ * the brightness is differentiated); others return RM_E_BADARG.  For modes 1 and 2 the reference's own gradient is
+ * NaN (x^(1/2.33) at the global minimum).
  * fp32 only (cam->dtype must be RM_DTYPE_F32).  grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
  * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT
@@ -265,10 +268,16 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                        const float* traj, const int32_t* nexec, const float* p_final,
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
                        float* grad_pos /*nullable [R,3]*/, float* grad_dirs /*nullable [R,3]*/,
-                       int32_t mode, int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags,
+                       float* grad_qdir /*nullable [R,4]: per-ray dL/d(orientation) through the shader's own use of the
+                                          pose (modes 3, 6, 7); sum the rows of a camera with rm_sum_rows*/,
+                       const void* cmap, int32_t cmap_size, int32_t cmap_dtype /*modes 6, 7: as in the forward call*/,
+                       int32_t mode, int32_t degree, int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags,
                        int32_t* tile_cost /*nullable out [T]: reverse march steps each tile's wave walked*/,
                        float* hard_ws /*nullable: rm_bwd_hard_floats(hard_capacity, steps) floats*/,
                        int64_t hard_capacity, void* stream);
+
+/* out[width] = sum over n_rows rows of rows[n_rows][width], fixed summation tree (deterministic). */
+int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream);
 
 /* Workspace of the deferred-ray path of rm_render_backward.  Rays whose march has not converged need a VJP at
  * every remaining step; walked by their own wave they are the critical path of the launch, so (with

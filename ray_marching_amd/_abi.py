@@ -85,7 +85,9 @@ _SIGNATURES = {
     "rm_shade_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
+                                     _P, _P, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
+    "rm_sum_rows": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "rm_bwd_hard_floats": (C.c_int64, [C.c_int64, C.c_int32]),
     "rm_camera_backward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
 }

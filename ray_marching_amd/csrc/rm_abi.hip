@@ -454,7 +454,8 @@ int rm_camera_backward(const RmCamera* cam, const float* orientation, const floa
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
-                       float* grad_pos, float* grad_dirs, int32_t mode,
+                       float* grad_pos, float* grad_dirs, float* grad_qdir, const void* cmap, int32_t cmap_size,
+                       int32_t cmap_dtype, int32_t mode, int32_t degree,
                        int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, int32_t* tile_cost,
                        float* hard_ws, int64_t hard_capacity, void* stream) {
 #ifdef RM_NO_BACKWARD
@@ -462,8 +463,11 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
 #else
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
   if (cam->dtype != RM_DTYPE_F32) return fail(RM_E_BADARG, "rm_render_backward: fp32 camera buffers only");
-  if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL))
-    return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (use modes 0 or 4)", mode);
+  const bool mapped = (mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
+  if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL || mode == RM_MODE_VIGNETTE || mapped))
+    return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (modes 0, 3, 4, 6, 7 have)", mode);
+  if (mapped && (!cmap || cmap_size <= 0 || cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64))
+    return fail(RM_E_BADARG, "rm_render_backward: mode %d needs the colormap of the forward call", mode);
   if (!p_final || !grad_image || !partials || (steps > 0 && !traj)) return fail(RM_E_BADARG, "rm_render_backward: null buffer");
   rm::RenderArgs a;
   memset(&a, 0, sizeof(a));
@@ -471,7 +475,8 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
   a.grad_image = grad_image; a.partials = partials; a.minmax = work;
-  a.grad_pos = grad_pos; a.grad_dirs = grad_dirs; a.tile_cost = tile_cost;
+  a.grad_pos = grad_pos; a.grad_dirs = grad_dirs; a.grad_qdir = grad_qdir; a.tile_cost = tile_cost;
+  a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype; a.degree = degree;
   a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
   if (int e = pick_launch(rm::k_render_bwd<GB>, *scene, true, 128, &L)) return e;
@@ -515,6 +520,13 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   }
   return reduce_partials(*scene, partials, rows, grad_params, (hipStream_t)stream);
 #endif
+}
+
+int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream) {
+  if (!rows || !out || n_rows < 0 || n_rows > 0x7fffffff || width <= 0 || width > 65535)
+    return fail(RM_E_BADARG, "rm_sum_rows: bad args");
+  rm::k_reduce_partials<<<width, 256, 0, (hipStream_t)stream>>>(rows, (int)n_rows, width, out);
+  return launched("k_reduce_partials");
 }
 
 /* Host-side validation of a compiled program (host pointer).  The device copy a

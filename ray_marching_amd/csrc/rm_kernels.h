@@ -555,6 +555,7 @@ struct RenderArgs {
   float* partials;
   float* grad_pos;           // nullable [R,3]: dL/d(ray origin)   (feeds rm_camera_backward)
   float* grad_dirs;          // nullable [R,3]: dL/d(ray direction)
+  float* grad_qdir;          // nullable [R,4]: dL/d(orientation) through the SHADER's own use of the pose (modes 3, 6, 7)
   // rays parked by the forward kernel for k_render_parked (nullable / 0)
   int32_t* park_ray;         // [lists * shards][seg] band-output index
   float* park_p;             // [lists * shards][seg][3] iterate after the check step
@@ -1220,24 +1221,96 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     float c0 = 0.0f;
     V3 n; float lap;
     normals_forward(scene, T, p, c0, n, lap);
-    V3 gn;
+    V3 gn = mk3(0.0f, 0.0f, 0.0f);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
+    float gq0 = 0.0f, gq1 = 0.0f, gq2 = 0.0f, gq3 = 0.0f;     // direct dependence of the shader on the pose quaternion
     if (a.mode == RM_MODE_LAMBERTIAN) {
       float c = -dot_seq(v, n);
       float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
       gn = mk3(-g * v.x, -g * v.y, -g * v.z);
       gv = mk3(-g * n.x, -g * n.y, -g * n.z);                                    // direct dependence of the shader on v
-    } else {  // RM_MODE_NORMAL
+    } else if (a.mode == RM_MODE_NORMAL) {
       gn = mk3((fabsf(n.x) <= 1.0f) ? gi3.x * sgn0(n.x) : 0.0f,
                (fabsf(n.y) <= 1.0f) ? gi3.y * sgn0(n.y) : 0.0f,
                (fabsf(n.z) <= 1.0f) ? gi3.z * sgn0(n.z) : 0.0f);
+    } else if (a.mode == RM_MODE_VIGNETTE) {     // (v . col2(q))^3, shader.py:62-66; col2 = third column of QuaternionToSO3
+      const float w = ps.w, x = ps.qv.x, y = ps.qv.y, z = ps.qv.z;
+      const V3 c2 = mk3(2.0f * (w * y + x * z), 2.0f * (y * z - w * x), ((w * w - x * x) - y * y) + z * z);
+      const float d = dot_seq(v, c2);
+      const float gd = ((gi3.x + gi3.y) + gi3.z) * (3.0f * (d * d));
+      gv = mk3(gd * c2.x, gd * c2.y, gd * c2.z);
+      const V3 gc = mk3(gd * v.x, gd * v.y, gd * v.z);
+      gq0 = 2.0f * ((gc.x * y - gc.y * x) + gc.z * w);
+      gq1 = 2.0f * ((gc.x * z - gc.y * w) - gc.z * x);
+      gq2 = 2.0f * ((gc.x * w + gc.y * z) - gc.z * y);
+      gq3 = 2.0f * ((gc.x * x + gc.y * y) + gc.z * z);
+    } else {   // tangent (6) / spin (7): image = brightness * colormap[index]; the index is piecewise constant
+      ShadeIn si;
+      si.o = p; si.v = v; si.p = p; si.n = n; si.lap = 0.0f; si.dist = 0.0f; si.qw = ps.w; si.qv = ps.qv; si.col2 = v;
+      const Shaded sh = shade_pixel(a.mode, si, a.cmap_size, a.degree);
+      float c0, c1, c2;
+      if (a.cmap_dtype == RM_DTYPE_F64) {
+        const double* c = static_cast<const double*>(a.cmap) + 3 * (int64_t)sh.idx;
+        c0 = (float)c[0]; c1 = (float)c[1]; c2 = (float)c[2];
+      } else {
+        const V3 c = load3_t(a.cmap, sh.idx, a.cmap_dtype);
+        c0 = c.x; c1 = c.y; c2 = c.z;
+      }
+      const float gb = (gi3.x * c0 + gi3.y * c1) + gi3.z * c2;
+      // brightness = (re^2 + im^2).pow(1/2): grad * 0.5 / brightness into the sum of squares, 2 x into each term
+      const float gs = gb * (0.5f / sh.bright);
+      if (a.mode == RM_MODE_TANGENT) {           // shader.py:125-150
+        const float c = dot_seq(n, v);
+        const V3 tg = mk3((c * v.x) * -1.0f + n.x, (c * v.y) * -1.0f + n.y, (c * v.z) * -1.0f + n.z);
+        const V3 u = neg(ps.qv);                 // rotation by conj(q): local = tg + w t + u x t, t = 2 u x tg
+        const V3 pr = qrot(tg, ps.w, u);
+        const V3 gl = mk3(gs * (2.0f * pr.x), gs * (2.0f * pr.y), 0.0f);
+        const V3 t = 2.0f * cross(u, tg);
+        const V3 ugl = cross(u, gl);
+        const V3 gtg = (gl + 2.0f * cross(u, ugl)) - (2.0f * ps.w) * ugl;
+        const V3 gt = ps.w * gl + cross(gl, u);
+        const V3 gu = cross(t, gl) + 2.0f * cross(tg, gt);
+        gq0 = (gl.x * t.x + gl.y * t.y) + gl.z * t.z;
+        gq1 = -gu.x; gq2 = -gu.y; gq3 = -gu.z;
+        const float gtv = dot_seq(gtg, v);       // tg = n - (n.v) v
+        gn = mk3(gtg.x - gtv * v.x, gtg.y - gtv * v.y, gtg.z - gtv * v.z);
+        gv = mk3(-c * gtg.x - gtv * n.x, -c * gtg.y - gtv * n.y, -c * gtg.z - gtv * n.z);
+      } else {                                   // shader.py:157-171: r = (0, n) (x) conj(q)
+        const float q0 = ps.w, q1 = -ps.qv.x, q2 = -ps.qv.y, q3 = -ps.qv.z;
+        const float p1 = n.x, p2 = n.y, p3 = n.z;
+        const float r0 = -((p1 * q1 + p2 * q2) + p3 * q3);
+        const float r1 = (p1 * q0 + p2 * q3) - p3 * q2;
+        const float r2 = (p2 * q0 + p3 * q1) - p1 * q3;
+        const float r3 = (p1 * q2 + p3 * q0) - p2 * q1;
+        const float re = r0 * r0 - ((r1 * r1 + r2 * r2) + r3 * r3);
+        const float nv = norm3(mk3(r1, r2, r3));
+        const float im = (nv * r0) * 2.0f;
+        const float g_im = gs * (2.0f * im), g_re = gs * (2.0f * re);       // domain_colouring(imag, real): both squared alike
+        const float g0 = g_re * (2.0f * r0) + g_im * (2.0f * nv);
+        const float sv = (nv == 0.0f) ? 0.0f : (g_im * (2.0f * r0)) / nv;
+        const float g1 = g_re * (-2.0f * r1) + sv * r1, g2 = g_re * (-2.0f * r2) + sv * r2, g3 = g_re * (-2.0f * r3) + sv * r3;
+        gn = mk3(((-q1 * g0 + q0 * g1) - q3 * g2) + q2 * g3, ((-q2 * g0 + q3 * g1) + q0 * g2) - q1 * g3,
+                 ((-q3 * g0 - q2 * g1) + q1 * g2) + q0 * g3);
+        const float gc0 = (p1 * g1 + p2 * g2) + p3 * g3;
+        const float gc1 = (-p1 * g0 + p3 * g2) - p2 * g3;
+        const float gc2 = (-p2 * g0 - p3 * g1) + p1 * g3;
+        const float gc3 = (-p3 * g0 + p2 * g1) - p1 * g2;
+        gq0 = gc0; gq1 = -gc1; gq2 = -gc2; gq3 = -gc3;
+      }
     }
-    V3 lam = normals_backward(scene, T, p, gn, 0.0f, false);
-    int ne = a.nexec ? a.nexec[li] : a.steps;
-    int walked;
-    bool deferred;
-    lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
-                        a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
+    if (live && a.grad_qdir) {
+      float* gq = a.grad_qdir + 4 * li;
+      gq[0] = gq0; gq[1] = gq1; gq[2] = gq2; gq[3] = gq3;
+    }
+    V3 lam = mk3(0.0f, 0.0f, 0.0f);
+    int walked = 0;
+    bool deferred = false;
+    if (a.mode != RM_MODE_VIGNETTE) {            // the vignette does not depend on the surface at all
+      lam = normals_backward(scene, T, p, gn, 0.0f, false);
+      int ne = a.nexec ? a.nexec[li] : a.steps;
+      lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
+                          a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
+    }
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
     if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam);
     if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);

@@ -296,7 +296,7 @@ def camera_forward(ray_positions, ray_directions, orientation, translation):
 # fused frame
 # --------------------------------------------------------------------------
 _GLOBAL_MODES = (1, 2, 5)
-_FUSED_VJP_MODES = {0, 4}            # shader modes rm_render_backward differentiates through
+_FUSED_VJP_MODES = {0, 3, 4, 6, 7}   # shader modes rm_render_backward differentiates through (1, 2: the reference's gradient is NaN)
 _N_FIXED_ARGS = 18                   # Render.forward arguments in front of *leaves
 
 
@@ -411,7 +411,7 @@ class Render(torch.autograd.Function):
             # (the backward kernels read the live storages, which must still hold the forward's values)
             ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
             ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
-            ctx.precision = precision
+            ctx.precision, ctx.cmap, ctx.degree = precision, cmap, degree
         return image
 
     @staticmethod
@@ -434,6 +434,10 @@ class Render(torch.autograd.Function):
             need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             gpos = torch.empty_like(p_final) if need_pose else None
             gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
+            # modes 3, 6, 7 use the pose quaternion in the shader itself: per-ray dL/dq, summed per camera below
+            gqdir = torch.empty(p_final.shape[:-1] + (4,), dtype=torch.float32, device=dev) \
+                if (ctx.needs_input_grad[1] and ctx.mode in (3, 6, 7)) else None
+            cmap = ctx.cmap if ctx.mode in (6, 7) else None
             # deferred-ray workspace: room for one ray in eight (config 4 defers 2 %; the rest is walked in place)
             hard_cap = 0 if (bwd_hard_capacity == 0 or ctx.steps == 0) else \
                 (bwd_hard_capacity or min(1 << 21, max(4096, p_final.numel() // 3 // 8)))
@@ -444,12 +448,21 @@ class Render(torch.autograd.Function):
             _abi.check(cs.lib(True, ctx.precision).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
-                                               ctx.mode, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags,
+                                               _abi.ptr(gqdir), _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
+                                               0 if cmap is None else _abi.dtype_code(cmap.dtype),
+                                               ctx.mode, ctx.degree, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags,
                                                _abi.ptr(bwd_tile_cost_sink), _abi.ptr(hard), hard_cap, stream),
                        "rm_render_backward", cs.lib(True, ctx.precision))
         gq = gt = None
         if need_pose:
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+            if gqdir is not None:
+                n_cam, per_cam = gqdir.shape[0], gqdir[0].numel() // 4
+                direct = torch.empty((n_cam, 4), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    for c in range(n_cam):
+                        _abi.check(_lib.rm_sum_rows(_abi.ptr(gqdir[c]), per_cam, 4, _abi.ptr(direct[c]), stream), "rm_sum_rows")
+                gq = gq + direct
         gp_out = gprm[: prm.numel()] if (prm is not None and ctx.needs_input_grad[0]) else None
         leaf_grads, o = [], 0
         for k, p in enumerate(leaves):          # named_parameters() order = block order

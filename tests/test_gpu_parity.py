@@ -1046,3 +1046,43 @@ def test_deferred_rays_give_the_same_gradients(capacity, kernel_path):
         assert int(b[3].max()) <= int(a[3].max()) // 2          # the long walks moved to the parallel kernels
     for x, y in zip(a[0] + [a[1], a[2]], b[0] + [b[1], b[2]]):
         assert (x - y).abs().max().item() <= 2e-6 * max(1.0, x.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [3, 6, 7])
+def test_fused_vjp_of_vignette_tangent_and_spin_shaders(mode, kernel_path):
+    """Gradients through the fused frame for the shaders that use the camera pose themselves: vignette
+    ((v . col2(q))^3, shader.py:62-66), tangent and spin (brightness x colormap[index], shader.py:107-171; the
+    index is piecewise constant, so only the brightness carries a gradient) -- scene parameters, orientation
+    and translation vs CPU autograd on the oracle (= the reference's op stream)."""
+    h, w, steps = 40, 48, 48
+    spec = O.scene_test1_closed()
+    bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
+    cmap = torch.from_numpy(H.gold("cmap.npz")["cyclic_cmap"])
+    q0 = torch.nn.functional.normalize(torch.tensor([[0.98, 0.05, -0.12, 0.03]]), dim=-1)
+    t0 = torch.tensor([[0.15, -0.1, -1.2]])
+    wimg = torch.rand(1, h, w, 3, generator=torch.Generator().manual_seed(11 + mode), dtype=torch.float64)
+    spec_g = O.map_spec(spec, lambda x: x.clone().requires_grad_(True))
+    qc, tc = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    (O.render(spec_g, bufs, qc, tc, mode, 2, steps, H.EPS, cmap=cmap) * wimg).mean().backward()
+    module = H.spec_to_module(spec)
+    loop = H.make_loop(module, h, w)
+    loop.shader.cyclic_cmap = cmap.to(DEV)
+    _check_path(module, kernel_path)
+    qg, tg = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+    img = loop(qg, tg, mode, 2, steps)
+    assert img.dtype == (torch.float64 if mode in (6, 7) else torch.float32)
+    (img * wimg.to(DEV)).mean().backward()
+    for name, got, want in (("orientation", qg.grad, qc.grad), ("translation", tg.grad, tc.grad)):
+        if want is None:            # the vignette does not depend on the camera position
+            assert got is None or float(got.abs().max()) == 0.0
+            continue
+        scale = max(1e-6, want.abs().max().item())
+        err = (got.cpu() - want).abs().max().item()
+        print(f"mode {mode} grad {name}: |err|={err:.2e} (scale {scale:.2e})")
+        assert err <= 1e-4 * max(1.0, scale) and err <= 5e-3 * scale, (name, err, scale)
+    for (pname, want), (_, got) in zip(O.spec_parameters(spec_g), module.named_parameters()):
+        if want.grad is None:       # vignette: no scene parameter is involved
+            assert got.grad is None or float(got.grad.abs().max()) == 0.0, pname
+            continue
+        err = (got.grad.cpu() - want.grad).abs().max().item()
+        assert err <= 1e-4, (mode, pname, err)
