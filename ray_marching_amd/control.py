@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from . import ops
+from . import _abi, ops
 from .compiler import compiled_for
 from .rendering.ray_marching import PinholeCamera, SDFMarcher, SDFNormals
 from .rendering.shader import Shader
@@ -99,7 +99,7 @@ class RenderLoop(nn.Module):
     def __init__(self, scene, num_cameras: int = 1, px_width: int = 800, px_height: int = 800,
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
                  normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True,
-                 dynamic_tiles: bool = True, precision: str = "exact", rows=None):
+                 dynamic_tiles: bool = True, precision: str = "exact", rows=None, adaptive_order: int = 16):
         """Arguments of the reference's RenderLoop (control.py:198-208) plus kernel options.  ``rows=(r0, r1)``:
         this loop only ever renders that band of the frame (one rank of a row-tiled multi-GPU render) and keeps
         only that band of the camera buffers; ``forward`` then returns [N, r1-r0, W, 3]."""
@@ -119,12 +119,18 @@ class RenderLoop(nn.Module):
         if precision not in ("exact", "fast"):
             raise ValueError("precision must be 'exact' (bit-faithful to the reference's CPU op stream, default) or 'fast'")
         self.precision = precision
+        # frames deal their wave tiles longest-first, from the step counts an earlier frame recorded; the
+        # order is renewed every `adaptive_order` frames (0 = natural order always).  State per (band, step count,
+        # stream): two streams must never share an order buffer that one of them is rewriting.
+        self.adaptive_order = int(os.environ.get("RM_ADAPTIVE_ORDER", adaptive_order))      # env: A/B probes
+        self._order_state = {}
         self._f32_cache = {}
 
     # cached conversions live outside the module's picklable state (copy.deepcopy / torch.save of a RenderLoop)
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_f32_cache"] = {}
+        state["_order_state"] = {}
         return state
 
     def _f32_buffer(self, name: str) -> Tensor:
@@ -163,6 +169,46 @@ class RenderLoop(nn.Module):
             self._f32_cache["cmap"] = hit
         return hit[1]
 
+    def _tile_schedule(self, rp: Tensor, rows, steps: int):
+        """(tile_order, tile_cost, after) of the next inference frame.  Every `adaptive_order`-th frame records the
+        per-tile step counts and, right behind the frame on the same stream, sorts the tiles by decreasing cost
+        (rm_tile_order_from_cost); the frames in between are dealt in that order.  Any order renders the same
+        image, so a stale one (the camera moved) only costs the gain."""
+        n, h, w, _ = rp.shape
+        r0, r1 = rows if rows is not None else (0, h)
+        dev = rp.device
+        key = (r0, r1, steps, self.tile8x8, torch.cuda.current_stream(dev).cuda_stream)
+        st = self._order_state.get(key)
+        if st is None:
+            T = int(ops._lib.rm_wave_tiles(n, r1 - r0, w, ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles)))
+            # Where it pays (measured, profiles/ab_probe.py): the permutation costs every tile one more dependent L2
+            # round trip (order[position] before the ray loads: +18 us on the 1080p scene-2 frame, which gains
+            # nothing from it), and it shortens the tail of launches whose longest tiles are a large part of a wave's
+            # whole share: few tiles per wave (512^2 closed scene 1: 173 -> 118 us) or tiles whose per-step cost
+            # varies with the scene part they hit (32-primitive 8K band: 13.6 -> 11.1 ms).
+            worth = T <= 16384 or compiled_for(self.scene).n_instr >= 64
+            if T < 4096 or not worth:
+                st = {"T": 0}
+            else:
+                st = {"T": T, "cost": torch.empty(T, dtype=torch.int32, device=dev),
+                      "order": torch.empty(T, dtype=torch.int32, device=dev), "frame": 0, "valid": False}
+            self._order_state[key] = st
+        if not st["T"]:
+            return None, None, None
+        st["frame"] += 1
+        order = st["order"] if st["valid"] else None
+        if (st["frame"] - 1) % self.adaptive_order:
+            return order, None, None
+
+        def after():
+            with torch.cuda.device(dev):
+                _abi.check(ops._lib.rm_tile_order_from_cost(_abi.ptr(st["cost"]), st["T"], steps, _abi.ptr(st["order"]),
+                                                            _abi.current_stream(dev)), "rm_tile_order_from_cost")
+            st["valid"] = True
+        # the frame that records the cost reads the OLD order while the sort kernel that follows it on the same
+        # stream writes the new one in place: stream order makes that safe
+        return order, st["cost"], after
+
     def capture(self, mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None) -> CapturedFrame:
         """HIP-graph replay of one inference frame (see CapturedFrame)."""
         return CapturedFrame(self, mode, degree, marching_steps, rows)
@@ -188,6 +234,11 @@ class RenderLoop(nn.Module):
         # The kernels gather the parameter block from the nn.Parameter storages themselves (nothing to pack,
         # nothing to go stale); a training frame hands the Parameters to the autograd Function as its leaves.
         # Only parameters that cannot be read in place (other device / dtype) are packed with torch.cat.
+        if (self.adaptive_order > 0 and tile_order is None and tile_cost is None and self.dynamic_tiles
+                and self.early_out):
+            tile_order, tile_cost, after = self._tile_schedule(rp, rows, int(marching_steps))
+        else:
+            after = None
         params, leaves = None, ()
         if training or _AB_PACK:
             if _AB_PACK or cs.param_table(rp.device) is None:
@@ -198,6 +249,8 @@ class RenderLoop(nn.Module):
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
                                  self.precision, None, tile_order, tile_cost, leaves)
+        if after is not None:
+            after()
         out_dtype = self.camera.ray_positions.dtype
         if mode in (6, 7):
             out_dtype = torch.promote_types(out_dtype, self.shader.cyclic_cmap.dtype)

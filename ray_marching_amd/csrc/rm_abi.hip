@@ -522,6 +522,21 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
 #endif
 }
 
+int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order, void* stream) {
+  if (!tile_cost || !tile_order || n_tiles <= 0 || n_tiles > 0x7fffffff || max_cost < 0)
+    return fail(RM_E_BADARG, "rm_tile_order_from_cost: bad args");
+  const size_t lds = 32 * 1024 * sizeof(int);      // 128 KiB of gfx950's 160 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_tile_order),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute(k_tile_order): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  rm::k_tile_order<<<1, 1024, lds, (hipStream_t)stream>>>(tile_cost, (int)n_tiles, max_cost, tile_order);
+  return launched("k_tile_order");
+}
+
 int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream) {
   if (!rows || !out || n_rows < 0 || n_rows > 0x7fffffff || width <= 0 || width > 65535)
     return fail(RM_E_BADARG, "rm_sum_rows: bad args");

@@ -1029,6 +1029,48 @@ __global__ void __launch_bounds__(256) k_render_parked(RenderArgs a) {
     fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
 }
 
+// Longest-first dealing order from the previous frame's per-tile step counts: STABLE counting sort by descending
+// cost class (32 classes; one block, every thread owns a contiguous run of tiles and its own 32 counters in LDS), so
+// tiles of one class keep their natural, spatially coherent order (a scatter through atomics shuffled them and cost
+// the headline frame 5 %).  Any permutation renders the same image.
+__global__ void __launch_bounds__(1024) k_tile_order(const int32_t* __restrict__ cost, int n_tiles, int max_cost,
+                                                     int32_t* __restrict__ order) {
+  constexpr int kBins = 32;
+  extern __shared__ int s_hist[];                         // [kBins][blockDim.x]: bin-major, so the scan below is linear
+  const int nt = blockDim.x, t = threadIdx.x;
+  const int chunk = (n_tiles + nt - 1) / nt;
+  const int lo = t * chunk, hi = (lo + chunk < n_tiles) ? lo + chunk : n_tiles;
+  auto bin_of = [&](int c) {
+    c = c < 0 ? 0 : (c > max_cost ? max_cost : c);
+    return (kBins - 1) - (int)(((long long)c * kBins) / (max_cost + 1));    // bin 0 = the most expensive class
+  };
+  for (int b = 0; b < kBins; ++b) s_hist[b * nt + t] = 0;
+  for (int i = lo; i < hi; ++i) s_hist[bin_of(cost[i]) * nt + t] += 1;
+  __syncthreads();
+  // exclusive scan over (bin, thread) in that order: 32 * 1024 entries, by one wave, 512 entries per lane
+  if (t < 64) {
+    const int per = (kBins * nt) / 64;
+    int local = 0;
+    for (int k = 0; k < per; ++k) local += s_hist[t * per + k];
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (t >= o) incl += up;
+    }
+    int run = incl - local;
+    for (int k = 0; k < per; ++k) {
+      const int h = s_hist[t * per + k];
+      s_hist[t * per + k] = run;
+      run += h;
+    }
+  }
+  __syncthreads();
+  for (int i = lo; i < hi; ++i) {
+    const int b = bin_of(cost[i]);
+    order[s_hist[b * nt + t]++] = i;
+  }
+}
+
 // second pass for the globally normalised shaders
 __global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
   float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
