@@ -11,6 +11,12 @@ import glob
 import json
 import os
 import shutil
+
+
+def newest(pattern):
+    """gpurun merges every run into gpurun_out/: take the latest file of a kind"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
 import sys
 from collections import defaultdict
 
@@ -19,13 +25,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 out = os.path.join(root, "profiles")
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
 
 
 def counters(sub):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     agg = defaultdict(list)
     if not f:
         return agg

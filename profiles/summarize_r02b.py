@@ -2,18 +2,24 @@
 r02_fp16_frame_kernel_stats.csv"""
 import csv, glob, json, os, shutil
 from collections import defaultdict
+
+
+def newest(pattern):
+    """gpurun merges every run into gpurun_out/: take the latest file of a kind"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_r02b")
 out = os.path.join(root, "profiles")
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_bwd_kernel_stats.csv"))
-shutil.copy(glob.glob(os.path.join(src, "fp16", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_fp16_frame_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_bwd_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "fp16", "*", "*_kernel_stats.csv"))[0], os.path.join(out, "r02_fp16_frame_kernel_stats.csv"))
 # FETCH_SIZE correction measured in the same round on k_camera_fwd (profiles/r02_pmc_summary.json)
 corr = json.load(open(os.path.join(out, "r02_pmc_summary.json")))
 ff, wf = corr["FETCH_SIZE_correction"], corr["WRITE_SIZE_correction"]
 res = defaultdict(dict)
 for sub, name, f in (("pmc_fetch", "FETCH_SIZE", ff), ("pmc_write", "WRITE_SIZE", wf)):
     acc = defaultdict(list)
-    for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for path in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == name:
                 acc[r["Kernel_Name"].split("<")[0].replace("void ", "")].append(float(r["Counter_Value"]))

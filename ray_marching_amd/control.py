@@ -230,6 +230,8 @@ class RenderLoop(nn.Module):
         training = torch.is_grad_enabled() and (orientations.requires_grad or translations.requires_grad
                                                 or any(p.requires_grad for p in cs.leaves))
         rp, rd = self._io_buffers(training)
+        ops._require_device(rp, "camera buffers")          # no CPU path: fail here, with the reason, not in a stream query
+        ops._require_device(orientations, "orientations")
         cmap = self._cmap(rp.device) if mode in (6, 7) else None
         # The kernels gather the parameter block from the nn.Parameter storages themselves (nothing to pack,
         # nothing to go stale); a training frame hands the Parameters to the autograd Function as its leaves.

@@ -464,11 +464,15 @@ class Render(torch.autograd.Function):
                         _abi.check(_lib.rm_sum_rows(_abi.ptr(gqdir[c]), per_cam, 4, _abi.ptr(direct[c]), stream), "rm_sum_rows")
                 gq = gq + direct
         gp_out = gprm[: prm.numel()] if (prm is not None and ctx.needs_input_grad[0]) else None
-        leaf_grads, o = [], 0
-        for k, p in enumerate(leaves):          # named_parameters() order = block order
-            n = p.numel()
-            leaf_grads.append(gprm[o:o + n].view(p.shape).to(p.dtype) if ctx.needs_input_grad[_N_FIXED_ARGS + k] else None)
-            o += n
+        leaf_grads = []
+        if leaves:                              # named_parameters() order = block order: one split, then views
+            pieces = torch.split(gprm[: cs.n_params], [p.numel() for p in leaves])
+            for k, (p, g) in enumerate(zip(leaves, pieces)):
+                if not ctx.needs_input_grad[_N_FIXED_ARGS + k]:
+                    leaf_grads.append(None)
+                    continue
+                g = g.view(p.shape)
+                leaf_grads.append(g if p.dtype == torch.float32 else g.to(p.dtype))
         return (gp_out, gq, gt) + (None,) * (_N_FIXED_ARGS - 3) + tuple(leaf_grads)
 
 
