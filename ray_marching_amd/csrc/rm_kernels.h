@@ -189,8 +189,9 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 // (measured: without the snapshot test 30% of wave tiles ran all 128 steps of config 2).
 // The wave leaves when ALL 64 rays have a known period; each lane is then advanced by
 // (remaining mod lambda) < lambda further steps so it lands on exactly the iterate the full
-// loop would have produced.  With a trajectory being recorded (backward) only the fixed point
-// exit is taken (p_j = p_final for j >= nexec).
+// loop would have produced.  With a trajectory being recorded (backward) the same exits are taken and the
+// iterates of steps >= nexec are not stored: the reverse sweep uses p_final for them (exact for a fixed point,
+// an ulp or two off inside a cycle between neighbouring floats -- a VJP argument, tolerance 1e-4).
 #ifndef RM_EARLY_DENSE_STEPS
 #define RM_EARLY_DENSE_STEPS 8    // look for cycles after every 2nd step up to here, after every 4th from then on
 #endif                            // (>= 4: the snapshot refreshes at steps 2 and 4 happen inside those looks)
@@ -242,7 +243,10 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
       // a fixed point is a cycle of any length; a wave leaves at most 3 steps later than it could.
       // branch-free per-lane bookkeeping (selects, no exec-mask juggling)
       const bool fixed = same_bits(pn, p);
-      const bool cyc = !traj && same_bits(pn, snap);
+      // (also while a trajectory is recorded: the reverse sweep then reads p_final for every step >= nexec, which
+      // is what a cycle between neighbouring floats is up to an ulp or two -- far inside the tolerance tau of its
+      // converged-tail handling, march_reverse)
+      const bool cyc = same_bits(pn, snap);
       const int found = fixed ? 1 : (cyc ? (i + 1 - snap_step) : 0);
       lambda = (lambda == 0) ? found : lambda;
       if constexpr (ParkF::kEnabled) {
@@ -430,8 +434,8 @@ __global__ void __launch_bounds__(256) k_march_bwd(RmScene sc, const float* __re
     V3 lam = live ? load3(gout, ic) : mk3(0.0f, 0.0f, 0.0f);
     V3 v = load3(dirs, ic);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
-    // With a trajectory recorded the forward leaves early only on a bitwise fixed point,
-    // so every iterate from nexec-1 on equals the last stored one.
+    // With a trajectory recorded, every iterate from nexec-1 on equals the last stored one up to the ulp or two
+    // of a cycle between neighbouring floats (exactly, for a fixed point).
     int ne = nexec ? nexec[ic] : steps;
     V3 pf = (ne > 0) ? load3(traj + 3 * (int64_t)(ne - 1) * n, ic) : mk3(0.0f, 0.0f, 0.0f);
     lam = march_reverse(scene, lam, v, pf, traj, n, ic, ne, steps, gdirs != nullptr, gv, false);
