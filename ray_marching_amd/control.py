@@ -186,7 +186,9 @@ class RenderLoop(nn.Module):
             # nothing from it), and it shortens the tail of launches whose longest tiles are a large part of a wave's
             # whole share: few tiles per wave (512^2 closed scene 1: 173 -> 118 us) or tiles whose per-step cost
             # varies with the scene part they hit (32-primitive 8K band: 13.6 -> 11.1 ms).
-            worth = T <= 16384 or compiled_for(self.scene).n_instr >= 64
+            # With hundreds of tiles per wave (the whole 8K frame in one launch) the tail is negligible again and the
+            # lookups only cost: 84.7 -> 89.9 ms.
+            worth = T <= 16384 or (compiled_for(self.scene).n_instr >= 64 and T <= 131072)
             if T < 4096 or not worth:
                 st = {"T": 0}
             else:
