@@ -299,3 +299,38 @@ def test_hip_band_renderer_under_a_real_process_group(tmp_path):
     whole(q, torch.tensor([[0.0, 0.0, -1.0]], device=DEV), 0, 1, 24).pow(2).sum().backward()
     for g, p in zip(got["grads"], scene.parameters()):
         assert (g - p.grad.cpu()).abs().max().item() <= 2e-5 * max(1.0, p.grad.abs().max().item())
+
+
+def test_fp16_standalone_modules_equal_fp32_arithmetic_on_fp16_storage():
+    """rm_camera_forward / rm_march_forward / rm_normals_forward / rm_sdf_forward with dtype = F16: the
+    stand-alone modules of a .half() scene read and write fp16 arrays directly; results = the fp32 oracle on the
+    fp16-rounded inputs, rounded once to fp16, bit for bit."""
+    from ray_marching_amd.rendering.ray_marching import PinholeCamera, SDFMarcher, SDFNormals
+    h, w, steps = 36, 52, 40
+    r = lambda x: x.half().float()
+    spec = O.scene_test2()
+    spec16 = O.map_spec(spec, r)
+    module = H.spec_to_module(spec).to(DEV).half()
+    cam = PinholeCamera(2, w, h, H.PX * h, H.PX * w, H.PX * h).to(DEV).half()
+    gen = torch.Generator().manual_seed(2)
+    q = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0, 0.0]]) + 0.1 * torch.randn(2, 4, generator=gen), dim=-1).half()
+    t = (torch.tensor([[0.0, 0.0, -3.0]]) + 0.2 * torch.randn(2, 3, generator=gen)).half()
+    bufs = tuple(r(b) for b in O.camera_buffers(2, w, h, H.PX * h, H.PX * w, H.PX * h))
+    with torch.no_grad():
+        pos, frames, _, dirs = cam(q.to(DEV), t.to(DEV))
+        want_pos, want_frames, want_dirs = O.camera_forward(*bufs, q.float(), t.float())
+        assert pos.dtype == dirs.dtype == frames.dtype == torch.float16
+        assert torch.equal(pos.cpu(), want_pos.half()) and torch.equal(dirs.cpu(), want_dirs.half())
+        assert torch.equal(frames.cpu(), want_frames.half())
+        p = SDFMarcher(module)(pos, dirs, steps)                    # fp16 in, fp32 march, fp16 out
+        want_p = O.march(spec16, pos.float().cpu(), dirs.float().cpu(), steps).half()
+        assert p.dtype == torch.float16 and torch.equal(p.cpu(), want_p)
+        nrm = SDFNormals(module, H.EPS).to(DEV).half()
+        n, lap = nrm(p)
+        tetra = tuple(r(c) for c in O.tetra_constants(H.EPS))
+        want_n, want_lap = O.normals(spec16, p.float().cpu(), H.EPS, tetra)
+        assert n.dtype == lap.dtype == torch.float16
+        assert H.report("fp16 normals", n, want_n.half())[0] == 0.0          # report(): identical NaN patterns too
+        assert H.report("fp16 laplacian", lap, want_lap.half())[0] == 0.0
+        d = module(p)
+        assert d.dtype == torch.float16 and torch.equal(d.cpu(), O.sdf_eval(spec16, p.float().cpu()).half())
