@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 9
+#define RM_ABI_VERSION 10
 
 enum {
   RM_DTYPE_F32 = 0,
@@ -126,8 +126,21 @@ enum {
   RM_FLAG_EARLY_OUT = 1,   /* wave-uniform exit once every ray of the wave is in a proven bit-exact
                               cycle of the march map (results unchanged) */
   RM_FLAG_TILE8X8 = 2,     /* a wave covers an 8x8 pixel tile instead of 64 pixels of one row */
-  RM_FLAG_DYNAMIC_TILES = 4 /* waves draw tiles from the workspace's atomic tile queues instead
+  RM_FLAG_DYNAMIC_TILES = 4, /* waves draw tiles from the workspace's atomic tile queues instead
                               of a static stride */
+  RM_FLAG_REGEN = 8        /* rm_render_forward only: ray regeneration.  A wave is a pool of 64 ray slots; a lane whose
+                              ray has reached its final iterate is handed the next ray of a queue instead of idling
+                              until the slowest ray of its tile is done.  Two launches (march into `p_final`, then
+                              distance / normals / shader per tile); same image, bit for bit.  Pays where few rays
+                              of a tile settle late (the reference's default pose inside the torus: 2.5 ray-steps
+                              executed per step needed without it); costs a few per cent where tiles settle
+                              together.  Requires RM_FLAG_EARLY_OUT, RM_FLAG_TILE8X8, `minmax`, `p_final`,
+                              steps % 4 == 0, and no traj / nexec / parking.  `tile_order` matters more here than for
+                              the tile kernel: once the queues are dry idle lanes cannot be refilled, so the rays
+                              that march longest should be dealt first.  With this flag both arrays have one entry
+                              per RAY SLOT (64 * rm_wave_tiles() entries, slot = tile * 64 + lane of the 8x8 tile):
+                              `tile_cost` receives the steps each ray needed, `tile_order` is a permutation of the
+                              slots (rm_tile_order_from_cost sorts either kind). */
 };
 
 /* Workspace ("minmax") layout, uint32 words, prepared by rm_minmax_init before every launch
@@ -224,10 +237,15 @@ int64_t rm_park_floats(int64_t capacity);
 /* number of wave tiles (64-ray work units) of a band of `rows` rows: length of tile_order / tile_cost */
 int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t flags);
 
-/* tile_order for the NEXT frame from this frame's tile_cost (values 0 .. max_cost = the step count): tiles by
- * decreasing cost class, natural order inside a class (stable counting sort, one small kernel).  Worth it when consecutive frames are coherent (an interactive camera): +10 % at the reference's default
- * pose, where the tiles that run all steps are clustered; nothing to gain where tile cost is evenly spread. */
-int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order, void* stream);
+/* tile_order for the NEXT frame from this frame's tile_cost (values 0 .. max_cost = the step count): items by
+ * decreasing cost class (32 classes), natural order inside a class (stable counting sort).  Worth it when consecutive
+ * frames are coherent (an interactive camera).  Up to RM_ORDER_ONE_BLOCK items one block sorts them; beyond (the
+ * per-ray orders of RM_FLAG_REGEN) two multi-block kernels do, through `scratch` = device int32[RM_ORDER_SCRATCH_INTS]
+ * (NULL allowed for the small case). */
+#define RM_ORDER_ONE_BLOCK 131072
+#define RM_ORDER_SCRATCH_INTS 8192
+int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order,
+                            int32_t* scratch /*nullable*/, void* stream);
 
 /* workspace helpers: init (min=+inf, max=-inf, no NaN, all tile counters 0; the buffer holds
  * RM_WORK_WORDS uint32); decode to two floats {lo, hi};

@@ -48,7 +48,7 @@ class CapturedFrame:
         with torch.no_grad():
             self.params = None if self.table is not None else self.cs.pack_params(dev).clone()
         cmap = loop._cmap(dev) if self.mode in (6, 7) else None
-        flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles)
+        flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles, loop.regen)
         cs, table, params = self.cs, self.table, self.params
 
         class _Static:          # a CompiledScene view whose scene_struct points at THIS object's static buffers
@@ -99,7 +99,8 @@ class RenderLoop(nn.Module):
     def __init__(self, scene, num_cameras: int = 1, px_width: int = 800, px_height: int = 800,
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
                  normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True,
-                 dynamic_tiles: bool = True, precision: str = "exact", rows=None, adaptive_order: int = 16):
+                 dynamic_tiles: bool = True, precision: str = "exact", rows=None, adaptive_order: int = 16,
+                 regen: bool = False):
         """Arguments of the reference's RenderLoop (control.py:198-208) plus kernel options.  ``rows=(r0, r1)``:
         this loop only ever renders that band of the frame (one rank of a row-tiled multi-GPU render) and keeps
         only that band of the camera buffers; ``forward`` then returns [N, r1-r0, W, 3]."""
@@ -125,6 +126,9 @@ class RenderLoop(nn.Module):
         self.adaptive_order = int(os.environ.get("RM_ADAPTIVE_ORDER", adaptive_order))      # env: A/B probes
         self._order_state = {}
         self._f32_cache = {}
+        # ray regeneration (RM_FLAG_REGEN): lanes whose ray is done take the next ray of a queue instead of waiting
+        # for the slowest ray of their tile -- for poses where few rays per tile settle late
+        self.regen = bool(int(os.environ.get("RM_REGEN", int(regen))))
 
     # cached conversions live outside the module's picklable state (copy.deepcopy / torch.save of a RenderLoop)
     def __getstate__(self):
@@ -169,7 +173,7 @@ class RenderLoop(nn.Module):
             self._f32_cache["cmap"] = hit
         return hit[1]
 
-    def _tile_schedule(self, rp: Tensor, rows, steps: int):
+    def _tile_schedule(self, rp: Tensor, rows, steps: int, regen: bool = False):
         """(tile_order, tile_cost, after) of the next inference frame.  Every `adaptive_order`-th frame records the
         per-tile step counts and, right behind the frame on the same stream, sorts the tiles by decreasing cost
         (rm_tile_order_from_cost); the frames in between are dealt in that order.  Any order renders the same
@@ -177,7 +181,7 @@ class RenderLoop(nn.Module):
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
         dev = rp.device
-        key = (r0, r1, steps, self.tile8x8, torch.cuda.current_stream(dev).cuda_stream)
+        key = (r0, r1, steps, self.tile8x8, regen, torch.cuda.current_stream(dev).cuda_stream)
         st = self._order_state.get(key)
         if st is None:
             T = int(ops._lib.rm_wave_tiles(n, r1 - r0, w, ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles)))
@@ -188,12 +192,18 @@ class RenderLoop(nn.Module):
             # varies with the scene part they hit (32-primitive 8K band: 13.6 -> 11.1 ms).
             # With hundreds of tiles per wave (the whole 8K frame in one launch) the tail is negligible again and the
             # lookups only cost: 84.7 -> 89.9 ms.
-            worth = T <= 16384 or (compiled_for(self.scene).n_instr >= 64 and T <= 131072)
+            # Ray regeneration always wants it: once the queues are dry a pool's idle lanes stay idle, so the tiles
+            # with the longest rays have to go first.
+            worth = regen or T <= 16384 or (compiled_for(self.scene).n_instr >= 64 and T <= 131072)
             if T < 4096 or not worth:
                 st = {"T": 0}
             else:
+                if regen:
+                    T *= 64           # RM_FLAG_REGEN: one entry per ray slot (include/rm_abi.h)
                 st = {"T": T, "cost": torch.empty(T, dtype=torch.int32, device=dev),
-                      "order": torch.empty(T, dtype=torch.int32, device=dev), "frame": 0, "valid": False}
+                      "order": torch.empty(T, dtype=torch.int32, device=dev), "frame": 0, "valid": False,
+                      "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)
+                      if T > _abi.ORDER_ONE_BLOCK else None}
             self._order_state[key] = st
         if not st["T"]:
             return None, None, None
@@ -205,7 +215,8 @@ class RenderLoop(nn.Module):
         def after():
             with torch.cuda.device(dev):
                 _abi.check(ops._lib.rm_tile_order_from_cost(_abi.ptr(st["cost"]), st["T"], steps, _abi.ptr(st["order"]),
-                                                            _abi.current_stream(dev)), "rm_tile_order_from_cost")
+                                                            _abi.ptr(st["scratch"]), _abi.current_stream(dev)),
+                           "rm_tile_order_from_cost")
             st["valid"] = True
         # the frame that records the cost reads the OLD order while the sort kernel that follows it on the same
         # stream writes the new one in place: stream order makes that safe
@@ -238,11 +249,12 @@ class RenderLoop(nn.Module):
         # The kernels gather the parameter block from the nn.Parameter storages themselves (nothing to pack,
         # nothing to go stale); a training frame hands the Parameters to the autograd Function as its leaves.
         # Only parameters that cannot be read in place (other device / dtype) are packed with torch.cat.
+        flags = ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles, self.regen)
+        after = None
         if (self.adaptive_order > 0 and tile_order is None and tile_cost is None and self.dynamic_tiles
                 and self.early_out):
-            tile_order, tile_cost, after = self._tile_schedule(rp, rows, int(marching_steps))
-        else:
-            after = None
+            tile_order, tile_cost, after = self._tile_schedule(rp, rows, int(marching_steps),
+                                                               ops.regen_applies(flags, int(marching_steps), training))
         params, leaves = None, ()
         if training or _AB_PACK:
             if _AB_PACK or cs.param_table(rp.device) is None:
@@ -251,8 +263,7 @@ class RenderLoop(nn.Module):
                 leaves = cs.leaves
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
-                                 ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles), allreduce_minmax,
-                                 self.precision, None, tile_order, tile_cost, leaves)
+                                 flags, allreduce_minmax, self.precision, None, tile_order, tile_cost, leaves)
         if after is not None:
             after()
         out_dtype = self.camera.ray_positions.dtype

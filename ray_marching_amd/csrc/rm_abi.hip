@@ -326,9 +326,36 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     a.park_ray = reinterpret_cast<int32_t*>(park_ws);
     a.park_p = park_ws + park_seg * RM_PARK_LISTS * RM_PARK_SHARDS;
   }
+  const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
+  if (flags & RM_FLAG_REGEN) {
+    if (!(flags & RM_FLAG_EARLY_OUT) || !(flags & RM_FLAG_TILE8X8) || !minmax || !p_final || (steps & 3) || traj || nexec || park)
+      return fail(RM_E_BADARG, "rm_render_forward: RM_FLAG_REGEN needs EARLY_OUT, TILE8X8, minmax, p_final, steps %% 4 == 0 "
+                               "and no traj / nexec / parking");
+    if (wave_tiles * 64 >= ((int64_t)1 << 31)) return fail(RM_E_BADARG, "rm_render_forward: RM_FLAG_REGEN: too many rays");
+    if (tile_cost && hipMemsetAsync(tile_cost, 0, sizeof(int32_t) * wave_tiles * 64, (hipStream_t)stream) != hipSuccess)
+      return fail(RM_E_LAUNCH, "rm_render_forward: clearing tile_cost failed");
+    Launch LM, LF;
+    if (int e = pick_launch(rm::k_march_regen<G>, *scene, false, tune_block(), &LM)) return e;
+    if (int e = pick_launch(rm::k_render_finish<G>, *scene, false, tune_block(), &LF)) return e;
+    // persistent pools: as many blocks as the chip holds at once, never more than there are tiles to start with
+    int per_cu = 0;
+    int gm = 4 * cu_count();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_march_regen<G>, LM.block, LM.lds) == hipSuccess && per_cu > 0)
+      gm = per_cu * cu_count();
+    // (measured at 1080p, profiles/regen_probe.py: 7 blocks per CU 350 us, 5 -> 319, 4 -> 321, 3 -> 338: more pools in
+    // flight means more lanes left idle once the queues are dry)
+    if (gm > 5 * cu_count()) gm = 5 * cu_count();
+    if (env_set("RM_MAX_BLOCKS") && tune_max_blocks() > 0) gm = tune_max_blocks();
+    const int64_t tile_blocks = (wave_tiles + (LM.block >> 6) - 1) / (LM.block >> 6);
+    if (gm > tile_blocks) gm = (int)(tile_blocks < 1 ? 1 : tile_blocks);
+    rm::k_march_regen<G><<<gm, LM.block, LM.lds, (hipStream_t)stream>>>(a);
+    if (int e = launched("k_march_regen")) return e;
+    int gf = grid_for((wave_tiles + (LF.block >> 6) - 1) / (LF.block >> 6), tune_max_blocks() > 0 ? tune_max_blocks() : kMaxBlocks);
+    rm::k_render_finish<G><<<gf, LF.block, LF.lds, (hipStream_t)stream>>>(a);
+    return launched("k_render_finish");
+  }
   Launch L;
   if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
-  const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
   if (tune_max_blocks() > 0 && (flags & RM_FLAG_DYNAMIC_TILES) && minmax && !env_set("RM_MAX_BLOCKS")) {
@@ -522,19 +549,32 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
 #endif
 }
 
-int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order, void* stream) {
+int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order,
+                            int32_t* scratch, void* stream) {
   if (!tile_cost || !tile_order || n_tiles <= 0 || n_tiles > 0x7fffffff || max_cost < 0)
     return fail(RM_E_BADARG, "rm_tile_order_from_cost: bad args");
-  const size_t lds = 32 * 1024 * sizeof(int);      // 128 KiB of gfx950's 160 KiB
+  const size_t lds = (32 * 1024 + 32) * sizeof(int);      // 128 KiB of gfx950's 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_tile_order),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_order_scatter),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute(k_tile_order): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  rm::k_tile_order<<<1, 1024, lds, (hipStream_t)stream>>>(tile_cost, (int)n_tiles, max_cost, tile_order);
-  return launched("k_tile_order");
+  if (n_tiles <= RM_ORDER_ONE_BLOCK) {
+    rm::k_tile_order<<<1, 1024, lds, (hipStream_t)stream>>>(tile_cost, (int)n_tiles, max_cost, tile_order);
+    return launched("k_tile_order");
+  }
+  if (!scratch) return fail(RM_E_BADARG, "rm_tile_order_from_cost: more than %d items need the scratch buffer", RM_ORDER_ONE_BLOCK);
+  int blocks = (int)((n_tiles + 16383) / 16384);
+  if (blocks > RM_ORDER_SCRATCH_INTS / 32) blocks = RM_ORDER_SCRATCH_INTS / 32;
+  rm::k_order_count<<<blocks, 1024, 0, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch);
+  if (int e = launched("k_order_count")) return e;
+  rm::k_order_scatter<<<blocks, 1024, lds, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch, tile_order);
+  return launched("k_order_scatter");
 }
 
 int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream) {

@@ -587,9 +587,8 @@ RM_DEV int64_t wave_tiles(const RenderArgs& a) {
   return ((int64_t)a.cam.num_cameras * rows * W + 63) >> 6;
 }
 
-RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t wave_tile, int& cam, int& row, int& col) {
+RM_DEV bool ray_of_tile_lane(const RenderArgs& a, int64_t wave_tile, int lane, int& cam, int& row, int& col) {
   const int W = a.cam.width, rows = a.row_end - a.row_begin;
-  const int lane = threadIdx.x & 63;
   if (a.flags & RM_FLAG_TILE8X8) {
     const int tw = (W + 7) >> 3, th = (rows + 7) >> 3;
     int64_t per_cam = (int64_t)tw * th;
@@ -607,6 +606,10 @@ RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t wave_tile, int& cam, int& r
   row = (int)(r / W);
   col = (int)(r - (int64_t)row * W);
   return cam < a.cam.num_cameras;
+}
+
+RM_DEV bool ray_of_lane(const RenderArgs& a, int64_t wave_tile, int& cam, int& row, int& col) {
+  return ray_of_tile_lane(a, wave_tile, threadIdx.x & 63, cam, row, col);
 }
 
 // Dynamic tile distribution.  The bit-exact early-out makes tile cost vary ~6x (config 2: 30% of
@@ -900,7 +903,7 @@ struct MinMaxAcc {
 // distance, normals / Laplacian, shader, stores (control.py:244-257)
 template <class SceneT>
 RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T, const TileRays& r, V3 p, int nexec,
-                        MinMaxAcc& mm) {
+                        MinMaxAcc& mm, bool store_p = true) {
   float dist = scene.eval(p);
   V3 n = mk3(0.0f, 0.0f, 0.0f);
   float lap = 0.0f;
@@ -919,7 +922,7 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   if (r.live) {
     if (global) store3(a.first_pass, r.li, out);          // rm_shade_finish normalises into `image`
     else store_shaded(a.image, a.image_dtype, r.li, sh, a.cmap, a.cmap_dtype);
-    if (a.p_final) store3(a.p_final, r.li, p);
+    if (store_p && a.p_final) store3(a.p_final, r.li, p);
     if (a.nexec) a.nexec[r.li] = nexec;
     if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
       mm.saw_nan |= (out.x != out.x);
@@ -1033,6 +1036,184 @@ __global__ void __launch_bounds__(256) k_render_parked(RenderArgs a) {
     fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
 }
 
+// ---- ray regeneration (RM_FLAG_REGEN) -----------------------------------------------------------------------
+// The wave-uniform exit of `march` keeps 64 lanes busy until the LAST ray of the tile has a proven period: at the
+// reference's default pose (0,0,1) 2.49 ray-steps are executed per ray-step needed (profiles/settle_probe.py).  Here a
+// wave is a pool of 64 ray slots instead of a tile: a lane whose ray has reached its final iterate stores it and is
+// handed the next ray of a queue (one returning atomic per wave and refill, for all free lanes together), so the
+// lanes stay full while any ray is left.  Only the march lives here: the final iterates go to `p_final` and
+// k_render_finish does distance / normals / shader per 8x8 tile with full, coherent waves (those ~7 uncullable
+// evaluations would otherwise run at the pool's partial occupancy).
+//
+// Per-lane bookkeeping replaces the wave-uniform one: local step count k (a multiple of 4 at every look), snapshot
+// for Brent's cycle search refreshed at k = 4, 8, 16, ..., and `stop` = the local step at which the lane holds
+// exactly the iterate the full S-step loop would end on (k + (S - k) mod lambda once a period lambda is proven at k).
+// The iteration itself is the same instruction stream per ray, so the image is bit-identical to k_render_fwd's.
+#ifndef RM_REGEN_MIN_FREE
+#define RM_REGEN_MIN_FREE 16      // refill when at least this many lanes of the wave are idle
+#endif
+
+// Queue q owns the dealing positions q, q + 64, q + 128, ... like the tile queues (so every queue hands its tiles out
+// in the global dealing order: longest first when a tile_order is given), 64 ray slots per position.  A draw returns
+// queue-local slots; slot s of queue q is lane s % 64 of position q + 64 (s / 64).
+RM_DEV uint32_t slot_queue_size(int64_t ntiles, int q) { return 64u * queue_size(ntiles, q); }
+
+// `m` consecutive slots of one queue for this wave (fewer at its end: `count`); -1 when every queue is drained.
+// Same structure as grab_wave_tile: counters only grow, every slot is handed out once, the grid always drains.
+RM_DEV int64_t grab_ray_slots(uint32_t* work, int64_t ntiles, int m, int& q, int& count) {
+  const int lane = threadIdx.x & 63;
+  uint32_t* ctr = work + RM_WORK_QUEUE_BASE;
+  for (int attempt = 0; attempt < 4 * RM_WORK_QUEUES; ++attempt) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&ctr[q * RM_WORK_QUEUE_STRIDE], (uint32_t)m);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + 64u * first_positions(q);
+    const uint32_t size = slot_queue_size(ntiles, q);
+    if (t < size) {
+      count = (size - t < (uint32_t)m) ? (int)(size - t) : m;
+      return (int64_t)t;
+    }
+    uint32_t c = __hip_atomic_load(&ctr[lane * RM_WORK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long avail = __ballot(c + 64u * first_positions(lane) < slot_queue_size(ntiles, lane));
+    if (avail == 0ull) return -1;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int r = (int)(((wave * 2654435761u) >> 20) + attempt * 17) & 63;
+    unsigned long long rot = (r == 0) ? avail : ((avail >> r) | (avail << (64 - r)));
+    q = (r + __builtin_ctzll(rot)) & 63;
+  }
+  for (int k = 0; k < RM_WORK_QUEUES; ++k) {     // not reached in practice: definitive sweep
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&ctr[k * RM_WORK_QUEUE_STRIDE], (uint32_t)m);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + 64u * first_positions(k);
+    const uint32_t size = slot_queue_size(ntiles, k);
+    if (t < size) {
+      q = k;
+      count = (size - t < (uint32_t)m) ? (int)(size - t) : m;
+      return (int64_t)t;
+    }
+  }
+  return -1;
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
+  const int S = a.steps;                          // a multiple of 4 (checked on the host)
+  const int lane = threadIdx.x & 63;
+  const int64_t ntiles = wave_tiles(a);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int q = (int)(wave & (RM_WORK_QUEUES - 1));
+  bool open = true, first = true;
+  // the ray of this lane
+  bool has = false;
+  int64_t li = 0;
+  int item = 0;                                   // ray slot: tile * 64 + lane of the tile
+  V3 p = mk3(0.0f, 0.0f, 0.0f), v = p, snap = p;
+  int k = 0, stop = 0, lambda = 0, snap_step = 0, next_snap = 4;
+  float move = __builtin_nanf(""), vn = 0.0f;
+  int it = 0;                                     // steps this wave has walked (cull knowledge is dropped every 16th)
+#ifdef RM_REGEN_STATS
+  unsigned st_groups = 0, st_lanes = 0, st_refills = 0, st_tail_groups = 0, st_tail_lanes = 0;
+#endif
+  for (;;) {
+    if (has && k >= stop) {                       // final iterate reached: hand it to k_render_finish
+      store3(a.p_final, li, p);
+      if (a.tile_cost) a.tile_cost[item] = stop;     // steps this ray needed (slots outside the image: zeroed by the host)
+      has = false;
+    }
+    const unsigned long long freem = __ballot(!has);
+    const int nfree = __popcll(freem);
+    if (!open && nfree == 64) break;
+#ifdef RM_REGEN_STATS
+    if (open && nfree >= RM_REGEN_MIN_FREE) ++st_refills;
+    else { ++st_groups; st_lanes += 64 - nfree; if (!open) { ++st_tail_groups; st_tail_lanes += 64 - nfree; } }
+#endif
+    if (open && nfree >= RM_REGEN_MIN_FREE) {
+      int count = 0;
+      int64_t base = -1;
+      if (first) {                                // static first draw: position wave/64 of the home queue, no atomic
+        first = false;
+        const uint32_t t = (uint32_t)(wave >> 6) * 64u, size = slot_queue_size(ntiles, q);
+        if (t < size) { base = (int64_t)t; count = (size - t < 64u) ? (int)(size - t) : 64; }
+      }
+      if (base < 0) base = grab_ray_slots(a.minmax, ntiles, nfree, q, count);
+      if (base < 0) {
+        open = false;
+      } else {
+        const int rank = __popcll(freem & ((1ull << lane) - 1ull));
+        const int64_t slot = base + rank;
+        int cam = 0, row = 0, col = 0;
+        bool take = !has && rank < count;
+        // dealing order (tile_order, here one entry per RAY SLOT = tile * 64 + lane of the tile): the rays that march
+        // longest first, so that what is left when the queues run dry are rays that settle within a few steps -- a
+        // pool cannot refill its idle lanes any more by then
+        const int64_t pos = ((int64_t)q + (slot >> 6) * RM_WORK_QUEUES) * 64 + (slot & 63);
+        if (take) item = a.tile_order ? a.tile_order[pos] : (int)pos;
+        take = take && ray_of_tile_lane(a, item >> 6, item & 63, cam, row, col);
+        if (take) {
+          li = ((int64_t)cam * rows + row) * W + col;
+          const int64_t gi = ((int64_t)cam * H + (row + a.row_begin)) * W + col;
+          V3 o, d;
+          Pose ps;
+          if (a.cam.dtype == RM_DTYPE_F16) load_ray_and_pose<_Float16>(a, gi, cam, o, d, ps);
+          else load_ray_and_pose<float>(a, gi, cam, o, d, ps);
+          p = qrot(o, ps.w, ps.qv) + ps.t;        // PinholeCamera.forward (ray_marching.py:58-62)
+          v = qrot(d, ps.w, ps.qv);
+          vn = 1.0001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+          move = __builtin_nanf("");
+          snap = p; snap_step = 0; next_snap = 4; lambda = 0; k = 0; stop = S;
+          has = true;
+        }
+      }
+      continue;                                   // (a ray of zero steps retires at once; an empty draw tries again)
+    }
+    const bool act = has && k < stop;
+    if (act) {
+      V3 prev = p;
+      for (int j = 0; j < 4; ++j) {
+        const float f = scene.eval_near(p, ((it + j) & 15) ? move : __builtin_nanf(""));
+        move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
+        prev = p;
+        p = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
+      }
+      k += 4;
+      if (lambda == 0) {
+        const int found = same_bits(p, prev) ? 1 : (same_bits(p, snap) ? (k - snap_step) : 0);
+        if (found) { lambda = found; stop = k + (S - k) % found; }
+      }
+      if (k == next_snap) { snap = p; snap_step = k; next_snap <<= 1; }
+    }
+    it += 4;
+  }
+#ifdef RM_REGEN_STATS
+  if (lane == 0) {
+    atomicAdd(&a.minmax[8], st_groups); atomicAdd(&a.minmax[9], st_lanes); atomicAdd(&a.minmax[10], st_refills);
+    atomicAdd(&a.minmax[11], st_tail_groups); atomicAdd(&a.minmax[12], st_tail_lanes);
+    atomicMax(&a.minmax[13], st_groups); atomicMax(&a.minmax[14], st_tail_groups);
+  }
+#endif
+}
+
+// distance / normals / shader of the final iterates k_march_regen left in p_final: one 8x8 tile per wave, static
+// striding (every tile costs the same here)
+template <class Cfg>
+__global__ void __launch_bounds__(256) k_render_finish(RenderArgs a) {
+  typename Cfg::Store store;
+  auto scene = Cfg::setup(a.scene, rm_smem, store);
+  Tetra T = load_tetra(a.tetra);
+  MinMaxAcc mm{__builtin_inff(), -__builtin_inff(), false};
+  const int64_t ntiles = wave_tiles(a);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+    TileRays r = load_tile_rays(a, tile);
+    const V3 p = load3(a.p_final, r.li);
+    finish_tile(a, scene, T, r, p, a.steps, mm, false);
+  }
+  if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
+    fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
+}
+
 // Longest-first dealing order from the previous frame's per-tile step counts: STABLE counting sort by descending
 // cost class (32 classes; one block, every thread owns a contiguous run of tiles and its own 32 counters in LDS), so
 // tiles of one class keep their natural, spatially coherent order (a scatter through atomics shuffled them and cost
@@ -1072,6 +1253,102 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int32_t* __restrict__
   for (int i = lo; i < hi; ++i) {
     const int b = bin_of(cost[i]);
     order[s_hist[b * nt + t]++] = i;
+  }
+}
+
+// The same stable counting sort for item counts one block cannot hold (the per-ray orders of RM_FLAG_REGEN: 2 M items
+// for a 1080p frame): block b owns a contiguous chunk, thread t a contiguous run of it.  k_order_count leaves the
+// per-(block, class) totals in `counts`; k_order_scatter recounts, scans (class, thread) inside the block like
+// k_tile_order and adds the start of its (class, block) cell in the global class-major, block-minor layout.
+RM_DEV int order_bin(int c, int max_cost) {
+  c = c < 0 ? 0 : (c > max_cost ? max_cost : c);
+  return 31 - (int)(((long long)c * 32) / (max_cost + 1));                  // bin 0 = the most expensive class
+}
+
+__global__ void __launch_bounds__(1024) k_order_count(const int32_t* __restrict__ cost, int64_t n, int max_cost,
+                                                      int32_t* __restrict__ counts) {
+  __shared__ int s_tot[32];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = (b0 + chunk < n) ? b0 + chunk : n;
+  if (t < 32) s_tot[t] = 0;
+  __syncthreads();
+  int mine[32];
+#pragma unroll
+  for (int b = 0; b < 32; ++b) mine[b] = 0;
+  // strided over the block here (coalesced): only totals are needed
+  for (int64_t i = b0 + t; i < b1; i += blockDim.x) {
+    const int bin = order_bin(cost[i], max_cost);
+#pragma unroll
+    for (int b = 0; b < 32; ++b) mine[b] += (bin == b);
+  }
+#pragma unroll
+  for (int b = 0; b < 32; ++b) {
+    int v = mine[b];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((t & 63) == 0 && v) atomicAdd(&s_tot[b], v);
+  }
+  __syncthreads();
+  if (t < 32) counts[blockIdx.x * 32 + t] = s_tot[t];
+}
+
+__global__ void __launch_bounds__(1024) k_order_scatter(const int32_t* __restrict__ cost, int64_t n, int max_cost,
+                                                        const int32_t* __restrict__ counts, int32_t* __restrict__ order) {
+  constexpr int kBins = 32;
+  extern __shared__ int s_hist[];                         // [kBins][blockDim.x] + [kBins] cell starts
+  const int nt = blockDim.x, t = threadIdx.x;
+  int* s_base = s_hist + kBins * nt;
+  const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = (b0 + chunk < n) ? b0 + chunk : n;
+  const int64_t run = (chunk + nt - 1) / nt;
+  const int64_t lo = (b0 + t * run < b1) ? b0 + t * run : b1, hi = (lo + run < b1) ? lo + run : b1;
+  for (int b = 0; b < kBins; ++b) s_hist[b * nt + t] = 0;
+  for (int64_t i = lo; i < hi; ++i) s_hist[order_bin(cost[i], max_cost) * nt + t] += 1;
+  if (t < 64) {
+    // start of cell (class t, this block): all items of more expensive classes, then this class in earlier blocks
+    int total = 0, before = 0;
+    if (t < kBins)
+      for (int b = 0; b < (int)gridDim.x; ++b) {
+        const int c = counts[b * 32 + t];
+        total += c;
+        if (b < (int)blockIdx.x) before += c;
+      }
+    int incl = total;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (t >= o) incl += up;
+    }
+    if (t < kBins) s_base[t] = (incl - total) + before;
+  }
+  __syncthreads();
+  if (t < 64) {                                           // exclusive scan over (bin, thread), as in k_tile_order
+    const int per = (kBins * nt) / 64;
+    int local = 0;
+    for (int k = 0; k < per; ++k) local += s_hist[t * per + k];
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (t >= o) incl += up;
+    }
+    int runsum = incl - local;
+    for (int k = 0; k < per; ++k) {
+      const int h = s_hist[t * per + k];
+      s_hist[t * per + k] = runsum;
+      runsum += h;
+    }
+  }
+  __syncthreads();
+  // block-local position of (bin, thread) minus the block-local start of the bin + the global start of the cell
+  int shift[kBins];
+#pragma unroll
+  for (int b = 0; b < kBins; ++b) shift[b] = s_base[b] - s_hist[b * nt];
+  __syncthreads();
+  for (int64_t i = lo; i < hi; ++i) {
+    const int b = order_bin(cost[i], max_cost);
+    int sh = 0;
+#pragma unroll
+    for (int k = 0; k < kBins; ++k) sh = (k == b) ? shift[k] : sh;
+    order[sh + s_hist[b * nt + t]++] = (int32_t)i;
   }
 }
 

@@ -59,9 +59,15 @@ def live_params(cs: CompiledScene, device, *inputs):
     return None
 
 
-def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False) -> int:
+def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False, regen: bool = False) -> int:
     return ((_abi.FLAG_EARLY_OUT if early_out else 0) | (_abi.FLAG_TILE8X8 if tile8x8 else 0) |
-            (_abi.FLAG_DYNAMIC_TILES if dynamic_tiles else 0))
+            (_abi.FLAG_DYNAMIC_TILES if dynamic_tiles else 0) | (_abi.FLAG_REGEN if regen else 0))
+
+
+def regen_applies(flags: int, steps: int, record: bool) -> bool:
+    """Whether a frame with these flags can take the ray-regeneration kernels (include/rm_abi.h, RM_FLAG_REGEN)."""
+    need = _abi.FLAG_REGEN | _abi.FLAG_EARLY_OUT | _abi.FLAG_TILE8X8 | _abi.FLAG_DYNAMIC_TILES
+    return (flags & need) == need and not record and steps > 0 and steps % 4 == 0
 
 
 # --------------------------------------------------------------------------
@@ -364,14 +370,18 @@ class Render(torch.autograd.Function):
         first_pass = None
         if mode in _GLOBAL_MODES:
             first_pass = image if image_dtype == torch.float32 else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
-        p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if record else None
+        regen = regen_applies(flags, steps, record)
+        if not regen:
+            flags &= ~_abi.FLAG_REGEN
+        # training: saved for the reverse sweep; ray regeneration: where the march kernel leaves the final iterates
+        p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if (record or regen) else None
         traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
         nexec = torch.empty(R, dtype=torch.int32, device=dev) if record else None
         minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)   # global min/max words + dynamic tile counter
         # parking workspace (rays that never settle are finished by a dense second kernel): room for 2 R rays
         # over the 32 list segments; inference frames of >= 48 steps with the early-out only
         park_cap = 0
-        if park_rays and not record and steps >= 48 and (flags & _abi.FLAG_EARLY_OUT) and R >= 4096:
+        if park_rays and not record and not regen and steps >= 48 and (flags & _abi.FLAG_EARLY_OUT) and R >= 4096:
             park_cap = 2 * R
         park = torch.empty(int(_lib.rm_park_floats(park_cap)), dtype=torch.float32, device=dev) if park_cap else None
         with torch.cuda.device(dev):
@@ -395,6 +405,7 @@ class Render(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
                 sink.append((ev0, ev1))
+                globals()["fwd_last_work"] = minmax       # measurement runs: the workspace words of this frame
             if mode in _GLOBAL_MODES:
                 if allreduce_minmax is not None:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
