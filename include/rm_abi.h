@@ -128,6 +128,7 @@ enum {
   RM_FLAG_TILE8X8 = 2,     /* a wave covers an 8x8 pixel tile instead of 64 pixels of one row */
   RM_FLAG_DYNAMIC_TILES = 4, /* waves draw tiles from the workspace's atomic tile queues instead
                               of a static stride */
+  RM_FLAG_ORDER_PER_RAY = 16, /* with RM_FLAG_REGEN: `tile_order` has one entry per ray slot (below) instead of per tile */
   RM_FLAG_REGEN = 8        /* rm_render_forward only: ray regeneration.  A wave is a pool of 64 ray slots; a lane whose
                               ray has reached its final iterate is handed the next ray of a queue instead of idling
                               until the slowest ray of its tile is done.  Two launches (march into `p_final`, then
@@ -137,10 +138,13 @@ enum {
                               together.  Requires RM_FLAG_EARLY_OUT, RM_FLAG_TILE8X8, `minmax`, `p_final`,
                               steps % 4 == 0, and no traj / nexec / parking.  `tile_order` matters more here than for
                               the tile kernel: once the queues are dry idle lanes cannot be refilled, so the rays
-                              that march longest should be dealt first.  With this flag both arrays have one entry
-                              per RAY SLOT (64 * rm_wave_tiles() entries, slot = tile * 64 + lane of the 8x8 tile):
-                              `tile_cost` receives the steps each ray needed, `tile_order` is a permutation of the
-                              slots (rm_tile_order_from_cost sorts either kind). */
+                              that march longest should be dealt first.  With this flag `tile_cost` has one entry
+                              per RAY SLOT (64 * rm_wave_tiles() entries, slot = tile * 64 + lane of the 8x8 tile) and
+                              receives the steps each ray needed; rm_tile_score_from_ray_cost turns it into a score
+                              per tile for rm_tile_order_from_cost (robust under camera motion: WHICH rays of a tile
+                              march long changes with the least move, how many do not).  RM_FLAG_ORDER_PER_RAY:
+                              `tile_order` is a permutation of the ray slots instead (rm_tile_order_from_cost of the
+                              per-ray costs: the best order for a frame that is rendered again unchanged). */
 };
 
 /* Workspace ("minmax") layout, uint32 words, prepared by rm_minmax_init before every launch
@@ -242,6 +246,8 @@ int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t 
  * frames are coherent (an interactive camera).  Up to RM_ORDER_ONE_BLOCK items one block sorts them; beyond (the
  * per-ray orders of RM_FLAG_REGEN) two multi-block kernels do, through `scratch` = device int32[RM_ORDER_SCRATCH_INTS]
  * (NULL allowed for the small case). */
+int rm_tile_score_from_ray_cost(const int32_t* ray_cost /*[64 * n_tiles]*/, int64_t n_tiles, int32_t max_cost,
+                                int32_t* tile_score /*[n_tiles], values 0..31: sort with max_cost = 31*/, void* stream);
 #define RM_ORDER_ONE_BLOCK 131072
 #define RM_ORDER_SCRATCH_INTS 8192
 int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order,

@@ -26,20 +26,25 @@ def timeit(fn, reps):
     return best
 out = {}
 q = torch.tensor([[1.0,0,0,0]], device=dev)
-def pair(name, scene, h, w, t, mode, steps, rows=None, reps=20):
-    a, b = mk(scene, h, w, adaptive_order=0), mk(scene, h, w, regen=True)
+def pair(name, scene, h, w, t, mode, steps, rows=None, reps=32):
+    loops = {"tile": mk(scene, h, w, regen=False), "regen": mk(scene, h, w, regen=True),
+             "regen_per_ray": mk(scene, h, w, regen=True, order_per_ray=True), "auto": mk(scene, h, w)}
+    res = {}
     with torch.no_grad():
-        ia, ib = a(q, t, mode, 1, steps, rows=rows), b(q, t, mode, 1, steps, rows=rows)
-        same = bool(torch.equal(ia.view(torch.int32), ib.view(torch.int32)))
-        ta = timeit(lambda: a(q, t, mode, 1, steps, rows=rows), reps)
-        tb = timeit(lambda: b(q, t, mode, 1, steps, rows=rows), reps)
-    out[name] = {"tile_us": round(1e3 * ta, 1), "regen_us": round(1e3 * tb, 1), "same_bits": same}
+        ref = loops["tile"](q, t, mode, 1, steps, rows=rows)
+        for k, l in loops.items():
+            img = l(q, t, mode, 1, steps, rows=rows)
+            same = bool(torch.equal(img.view(torch.int32), ref.view(torch.int32)))
+            res[k + "_us"] = round(1e3 * timeit(lambda: l(q, t, mode, 1, steps, rows=rows), reps), 1)
+            if not same:
+                res[k + "_DIFFERS"] = True
+    out[name] = res
 s2 = make_test_scene2()
 for z in (-3.0, 1.0):
     pair("c2_z%%g" %% z, s2, 1080, 1920, torch.tensor([[0.0,0.0,z]], device=dev), 4, 128)
 pair("c2_z1_mode1", s2, 1080, 1920, torch.tensor([[0.0,0.0,1.0]], device=dev), 1, 128)
 pair("c4_fwd", make_closed_test_scene(), 512, 512, torch.tensor([[0.0,0.0,-1.0]], device=dev), 0, 64)
-pair("c5_band", make_many_primitive_scene(32), 4320, 7680, torch.tensor([[0.0,0.0,-4.5]], device=dev), 4, 256, rows=(1620, 2160), reps=3)
+pair("c5_band", make_many_primitive_scene(32), 4320, 7680, torch.tensor([[0.0,0.0,-4.5]], device=dev), 4, 256, rows=(1620, 2160), reps=16)
 print("RESULT " + json.dumps(out))
 ''' % ROOT
 

@@ -30,5 +30,12 @@ for z in (1.0, -3.0):
         for key, st in loop._order_state.items():
             if st.get("T"):
                 c, o = st["cost"].cpu(), st["order"].cpu()
-                print("   order state", key[:5], "valid", st["valid"], "cost histogram (16-step bins)", torch.bincount(c.clamp(0, 128) // 16, minlength=9).tolist(),
-                      "cost along the order (deciles)", [int(c[o[int(i * (len(o) - 1) / 10)]]) for i in range(11)])
+                if st["score"] is not None:
+                    sc = st["score"].cpu()
+                    tmax = c.view(-1, 64).max(dim=1).values
+                    nlong = (c.view(-1, 64) >= 96).sum(dim=1)
+                    dec = [int(i * (len(o) - 1) / 10) for i in range(11)]
+                    print("   tile order: score along the order (deciles)", [int(sc[o[i]]) for i in dec], "longest ray of the tile", [int(tmax[o[i]]) for i in dec],
+                          "long rays in the tile", [int(nlong[o[i]]) for i in dec], "tiles with a long ray", int((nlong > 0).sum()), "of", len(o))
+                else:
+                    print("   ray order: cost along the order (deciles)", [int(c[o[int(i * (len(o) - 1) / 10)]]) for i in range(11)])

@@ -26,7 +26,7 @@ OP_SMOOTH_BEGIN, OP_FOLD_LSE, OP_SMOOTH_END = 12, 13, 14
 OP_ROUND, OP_ONION = 15, 16
 OP_CULL_MIN = 17
 
-FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES, FLAG_REGEN = 1, 2, 4, 8
+FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES, FLAG_REGEN, FLAG_ORDER_PER_RAY = 1, 2, 4, 8, 16
 ORDER_ONE_BLOCK, ORDER_SCRATCH_INTS = 131072, 8192
 DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2      # RM_DTYPE_*
 _DTYPES = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.float64: DTYPE_F64}
@@ -78,6 +78,7 @@ _SIGNATURES = {
     "rm_park_floats": (C.c_int64, [C.c_int64]),
     "rm_wave_tiles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_tile_order_from_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P]),
+    "rm_tile_score_from_ray_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),

@@ -48,7 +48,7 @@ class CapturedFrame:
         with torch.no_grad():
             self.params = None if self.table is not None else self.cs.pack_params(dev).clone()
         cmap = loop._cmap(dev) if self.mode in (6, 7) else None
-        flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles, loop.regen)
+        flags = ops.default_flags(loop.early_out, loop.tile8x8, loop.dynamic_tiles, loop.regen is True, loop.order_per_ray)
         cs, table, params = self.cs, self.table, self.params
 
         class _Static:          # a CompiledScene view whose scene_struct points at THIS object's static buffers
@@ -60,20 +60,39 @@ class CapturedFrame:
 
         static = _Static()
 
-        def frame():
+        def frame(order=None, cost=None):
             return ops.render_frame(None, self.q, self.t, static, rp, rd, loop.normals.tetra(), cmap,
-                                    self.mode, self.degree, self.steps, rows, flags, None, loop.precision)
+                                    self.mode, self.degree, self.steps, rows, flags, None, loop.precision, None, order, cost)
 
+        # regen=True: the regeneration kernels need a dealing order that follows the camera.  Two graphs share the
+        # static buffers: the plain frame, and a frame that also records the ray costs and renews the order behind it;
+        # every `adaptive_order`-th replay is of the second kind.  ("auto" needs host decisions between frames and
+        # stays with the tile kernel under capture.)
+        self._calls, self.graph_record, self._order = 0, None, None
+        if ops.regen_applies(flags, self.steps, False) and loop.adaptive_order > 0:
+            st = loop._new_order_state(rp, rows, True)
+            self._order = st if st["T"] else None
+        self._period = loop.adaptive_order
+        st = self._order
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):
                     frame()                       # warm-up outside capture (library / allocator state)
+                if st is not None:                # first order (at the pose in the static buffers)
+                    frame(None, st["cost"])
+                    loop._renew_order(st, self.steps, dev)
             torch.cuda.current_stream(dev).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.image = frame()
+                self.image = frame(None if st is None else st["order"])
+            if st is not None:
+                self.graph_record = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_record, pool=self.graph.pool()):
+                    img = frame(st["order"], st["cost"])
+                    loop._renew_order(st, self.steps, dev)
+                    self.image.copy_(img)
 
     def __call__(self, orientations: Tensor, translations: Tensor) -> Tensor:
         """Render with the given pose; returns the graph's static output tensor [N,rows,W,3]
@@ -91,7 +110,11 @@ class CapturedFrame:
                     self._table_src = cur
             else:
                 self.params.copy_(self.cs.pack_params(self.params.device))
-        self.graph.replay()
+        self._calls += 1
+        if self.graph_record is not None and self._calls % self._period == 0:
+            self.graph_record.replay()
+        else:
+            self.graph.replay()
         return self.image
 
 
@@ -100,7 +123,7 @@ class RenderLoop(nn.Module):
                  focal_length: float = 17e-3, sensor_width: float = 17e-3, sensor_height: float = 17e-3,
                  normals_eps: float = 5e-2, early_out: bool = True, tile8x8: bool = True,
                  dynamic_tiles: bool = True, precision: str = "exact", rows=None, adaptive_order: int = 16,
-                 regen: bool = False):
+                 regen="auto", order_per_ray: bool = False):
         """Arguments of the reference's RenderLoop (control.py:198-208) plus kernel options.  ``rows=(r0, r1)``:
         this loop only ever renders that band of the frame (one rank of a row-tiled multi-GPU render) and keeps
         only that band of the camera buffers; ``forward`` then returns [N, r1-r0, W, 3]."""
@@ -126,15 +149,27 @@ class RenderLoop(nn.Module):
         self.adaptive_order = int(os.environ.get("RM_ADAPTIVE_ORDER", adaptive_order))      # env: A/B probes
         self._order_state = {}
         self._f32_cache = {}
-        # ray regeneration (RM_FLAG_REGEN): lanes whose ray is done take the next ray of a queue instead of waiting
-        # for the slowest ray of their tile -- for poses where few rays per tile settle late
-        self.regen = bool(int(os.environ.get("RM_REGEN", int(regen))))
+        # Ray regeneration (RM_FLAG_REGEN): lanes whose ray is done take the next ray of a queue instead of waiting
+        # for the slowest ray of their tile -- for poses where few rays per tile settle late.  True / False, or
+        # "auto": large inference frames time both kernels on the launch stream now and then and use the faster one
+        # (_choose_kernel).
+        regen = os.environ.get("RM_REGEN", regen)
+        if regen in ("0", "1"):
+            regen = bool(int(regen))
+        if regen not in (True, False, "auto"):
+            raise ValueError("regen must be True, False or 'auto'")
+        self.regen = regen
+        self._choice_state = {}
+        # its dealing order: per tile (how many of a tile's rays march long -- stable under camera motion), or per ray
+        # (which rays do: only right for a frame that is rendered again unchanged, a paused viewer)
+        self.order_per_ray = bool(int(os.environ.get("RM_ORDER_PER_RAY", int(order_per_ray))))
 
     # cached conversions live outside the module's picklable state (copy.deepcopy / torch.save of a RenderLoop)
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_f32_cache"] = {}
         state["_order_state"] = {}
+        state["_choice_state"] = {}
         return state
 
     def _f32_buffer(self, name: str) -> Tensor:
@@ -173,7 +208,44 @@ class RenderLoop(nn.Module):
             self._f32_cache["cmap"] = hit
         return hit[1]
 
-    def _tile_schedule(self, rp: Tensor, rows, steps: int, regen: bool = False):
+    # frames smaller than this never take the regeneration kernels in "auto" mode: a 1080p frame is 6 draws per pool
+    # lane, below ~1 M rays the pools hardly refill at all
+    REGEN_AUTO_MIN_RAYS = 1 << 20
+
+    def _choose_kernel(self, rp: Tensor, rows, steps: int):
+        """regen="auto": (use the regeneration kernels for this frame?, record the dealing order now?, list for the
+        frame's timing events or None).  Frames come in cycles of `adaptive_order` (16 if that is off): the first one
+        of a cycle runs the kernel NOT in use (and renews its dealing order, so that it is measured with an order as old
+        as it would be in use), the second one the kernel in use, both between timing events on the launch stream that
+        are looked at -- without waiting -- by later frames; the other kernel takes over when it was more than 3 %
+        faster.  A probe costs one frame in sixteen the difference between the two kernels."""
+        n, h, w, _ = rp.shape
+        r0, r1 = rows if rows is not None else (0, h)
+        key = (r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream)
+        st = self._choice_state.get(key)
+        if st is None:
+            st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}}
+        for name in list(st["pending"]):
+            pair = st["pending"][name]
+            if pair and pair[0][1].query():
+                st["ms"][name] = pair[0][0].elapsed_time(pair[0][1])
+                del st["pending"][name]
+        if len(st["ms"]) == 2:
+            if st["ms"]["other"] < 0.97 * st["ms"]["used"]:
+                st["regen"] = not st["regen"]
+            st["ms"] = {}
+        cycle = self.adaptive_order if self.adaptive_order > 0 else 16
+        phase = st["n"] % cycle
+        st["n"] += 1
+        if cycle > 1 and phase == 0:
+            st["ms"], st["pending"] = {}, {"other": []}
+            return (not st["regen"]), True, st["pending"]["other"]
+        if cycle > 1 and phase == 1:
+            st["pending"]["used"] = []
+            return st["regen"], False, st["pending"]["used"]
+        return st["regen"], False, None
+
+    def _tile_schedule(self, rp: Tensor, rows, steps: int, regen: bool = False, record_now: bool = False):
         """(tile_order, tile_cost, after) of the next inference frame.  Every `adaptive_order`-th frame records the
         per-tile step counts and, right behind the frame on the same stream, sorts the tiles by decreasing cost
         (rm_tile_order_from_cost); the frames in between are dealt in that order.  Any order renders the same
@@ -181,46 +253,63 @@ class RenderLoop(nn.Module):
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
         dev = rp.device
-        key = (r0, r1, steps, self.tile8x8, regen, torch.cuda.current_stream(dev).cuda_stream)
+        per_ray = regen and self.order_per_ray
+        key = (r0, r1, steps, self.tile8x8, regen, per_ray, torch.cuda.current_stream(dev).cuda_stream)
         st = self._order_state.get(key)
         if st is None:
-            T = int(ops._lib.rm_wave_tiles(n, r1 - r0, w, ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles)))
-            # Where it pays (measured, profiles/ab_probe.py): the permutation costs every tile one more dependent L2
-            # round trip (order[position] before the ray loads: +18 us on the 1080p scene-2 frame, which gains
-            # nothing from it), and it shortens the tail of launches whose longest tiles are a large part of a wave's
-            # whole share: few tiles per wave (512^2 closed scene 1: 173 -> 118 us) or tiles whose per-step cost
-            # varies with the scene part they hit (32-primitive 8K band: 13.6 -> 11.1 ms).
-            # With hundreds of tiles per wave (the whole 8K frame in one launch) the tail is negligible again and the
-            # lookups only cost: 84.7 -> 89.9 ms.
-            # Ray regeneration always wants it: once the queues are dry a pool's idle lanes stay idle, so the tiles
-            # with the longest rays have to go first.
-            worth = regen or T <= 16384 or (compiled_for(self.scene).n_instr >= 64 and T <= 131072)
-            if T < 4096 or not worth:
-                st = {"T": 0}
-            else:
-                if regen:
-                    T *= 64           # RM_FLAG_REGEN: one entry per ray slot (include/rm_abi.h)
-                st = {"T": T, "cost": torch.empty(T, dtype=torch.int32, device=dev),
-                      "order": torch.empty(T, dtype=torch.int32, device=dev), "frame": 0, "valid": False,
-                      "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)
-                      if T > _abi.ORDER_ONE_BLOCK else None}
-            self._order_state[key] = st
+            st = self._order_state[key] = self._new_order_state(rp, rows, regen)
         if not st["T"]:
             return None, None, None
         st["frame"] += 1
         order = st["order"] if st["valid"] else None
-        if (st["frame"] - 1) % self.adaptive_order:
+        if (st["frame"] - 1) % self.adaptive_order and not record_now:
             return order, None, None
-
-        def after():
-            with torch.cuda.device(dev):
-                _abi.check(ops._lib.rm_tile_order_from_cost(_abi.ptr(st["cost"]), st["T"], steps, _abi.ptr(st["order"]),
-                                                            _abi.ptr(st["scratch"]), _abi.current_stream(dev)),
-                           "rm_tile_order_from_cost")
-            st["valid"] = True
         # the frame that records the cost reads the OLD order while the sort kernel that follows it on the same
         # stream writes the new one in place: stream order makes that safe
-        return order, st["cost"], after
+        return order, st["cost"], lambda: self._renew_order(st, steps, dev)
+
+    def _new_order_state(self, rp: Tensor, rows, regen: bool):
+        """Buffers of one dealing order ({"T": 0} where none is kept)."""
+        n, h, w, _ = rp.shape
+        r0, r1 = rows if rows is not None else (0, h)
+        dev = rp.device
+        per_ray = regen and self.order_per_ray
+        T = int(ops._lib.rm_wave_tiles(n, r1 - r0, w, ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles)))
+        # Where it pays (measured, profiles/ab_probe.py): the permutation costs every tile one more dependent L2
+        # round trip (order[position] before the ray loads: +18 us on the 1080p scene-2 frame, which gains
+        # nothing from it), and it shortens the tail of launches whose longest tiles are a large part of a wave's
+        # whole share: few tiles per wave (512^2 closed scene 1: 173 -> 118 us) or tiles whose per-step cost
+        # varies with the scene part they hit (32-primitive 8K band: 13.6 -> 11.1 ms).
+        # With hundreds of tiles per wave (the whole 8K frame in one launch) the tail is negligible again and the
+        # lookups only cost: 84.7 -> 89.9 ms.
+        # Ray regeneration always wants it: once the queues are dry a pool's idle lanes stay idle, so the tiles
+        # with the longest rays have to go first.
+        worth = regen or T <= 16384 or (compiled_for(self.scene).n_instr >= 64 and T <= 131072)
+        if T < 4096 or not worth:
+            return {"T": 0}
+        # RM_FLAG_REGEN records one cost per ray slot (include/rm_abi.h) and is dealt by tile scores made of
+        # them, or -- order_per_ray -- by the ray costs themselves
+        n_cost = T * 64 if regen else T
+        n_order = T * 64 if per_ray else T
+        return {"T": T, "n_order": n_order, "cost": torch.empty(n_cost, dtype=torch.int32, device=dev),
+                "order": torch.empty(n_order, dtype=torch.int32, device=dev), "frame": 0, "valid": False,
+                "score": torch.empty(T, dtype=torch.int32, device=dev) if (regen and not per_ray) else None,
+                "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)
+                if n_order > _abi.ORDER_ONE_BLOCK else None}
+
+    @staticmethod
+    def _renew_order(st, steps: int, dev):
+        """st["cost"] (written by the frame just launched on this stream) -> st["order"], on the same stream."""
+        with torch.cuda.device(dev):
+            stream = _abi.current_stream(dev)
+            src, top = st["cost"], steps
+            if st["score"] is not None:
+                _abi.check(ops._lib.rm_tile_score_from_ray_cost(_abi.ptr(st["cost"]), st["T"], steps, _abi.ptr(st["score"]),
+                                                                stream), "rm_tile_score_from_ray_cost")
+                src, top = st["score"], 31
+            _abi.check(ops._lib.rm_tile_order_from_cost(_abi.ptr(src), st["n_order"], top, _abi.ptr(st["order"]),
+                                                        _abi.ptr(st["scratch"]), stream), "rm_tile_order_from_cost")
+        st["valid"] = True
 
     def capture(self, mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None) -> CapturedFrame:
         """HIP-graph replay of one inference frame (see CapturedFrame)."""
@@ -249,12 +338,21 @@ class RenderLoop(nn.Module):
         # The kernels gather the parameter block from the nn.Parameter storages themselves (nothing to pack,
         # nothing to go stale); a training frame hands the Parameters to the autograd Function as its leaves.
         # Only parameters that cannot be read in place (other device / dtype) are packed with torch.cat.
-        flags = ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles, self.regen)
+        steps = int(marching_steps)
+        regen, record_now, events = False, False, None
+        if self.regen and tile_order is None and tile_cost is None and ops.regen_applies(
+                ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles, True), steps, training):
+            if self.regen == "auto":
+                band = rows if rows is not None else (0, rp.shape[1])
+                if rp.shape[0] * (band[1] - band[0]) * rp.shape[2] >= self.REGEN_AUTO_MIN_RAYS:
+                    regen, record_now, events = self._choose_kernel(rp, rows, steps)
+            else:
+                regen = True
+        flags = ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles, regen, self.order_per_ray)
         after = None
         if (self.adaptive_order > 0 and tile_order is None and tile_cost is None and self.dynamic_tiles
                 and self.early_out):
-            tile_order, tile_cost, after = self._tile_schedule(rp, rows, int(marching_steps),
-                                                               ops.regen_applies(flags, int(marching_steps), training))
+            tile_order, tile_cost, after = self._tile_schedule(rp, rows, steps, regen, record_now)
         params, leaves = None, ()
         if training or _AB_PACK:
             if _AB_PACK or cs.param_table(rp.device) is None:
@@ -263,7 +361,7 @@ class RenderLoop(nn.Module):
                 leaves = cs.leaves
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
-                                 flags, allreduce_minmax, self.precision, None, tile_order, tile_cost, leaves)
+                                 flags, allreduce_minmax, self.precision, None, tile_order, tile_cost, leaves, events)
         if after is not None:
             after()
         out_dtype = self.camera.ray_positions.dtype

@@ -553,6 +553,8 @@ int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t m
                             int32_t* scratch, void* stream) {
   if (!tile_cost || !tile_order || n_tiles <= 0 || n_tiles > 0x7fffffff || max_cost < 0)
     return fail(RM_E_BADARG, "rm_tile_order_from_cost: bad args");
+  if (n_tiles > RM_ORDER_ONE_BLOCK && !scratch)
+    return fail(RM_E_BADARG, "rm_tile_order_from_cost: more than %d items need the scratch buffer", RM_ORDER_ONE_BLOCK);
   const size_t lds = (32 * 1024 + 32) * sizeof(int);      // 128 KiB of gfx950's 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
@@ -568,13 +570,19 @@ int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t m
     rm::k_tile_order<<<1, 1024, lds, (hipStream_t)stream>>>(tile_cost, (int)n_tiles, max_cost, tile_order);
     return launched("k_tile_order");
   }
-  if (!scratch) return fail(RM_E_BADARG, "rm_tile_order_from_cost: more than %d items need the scratch buffer", RM_ORDER_ONE_BLOCK);
   int blocks = (int)((n_tiles + 16383) / 16384);
   if (blocks > RM_ORDER_SCRATCH_INTS / 32) blocks = RM_ORDER_SCRATCH_INTS / 32;
   rm::k_order_count<<<blocks, 1024, 0, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch);
   if (int e = launched("k_order_count")) return e;
   rm::k_order_scatter<<<blocks, 1024, lds, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch, tile_order);
   return launched("k_order_scatter");
+}
+
+int rm_tile_score_from_ray_cost(const int32_t* ray_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_score, void* stream) {
+  if (!ray_cost || !tile_score || n_tiles <= 0 || n_tiles > 0x1ffffff || max_cost < 0)
+    return fail(RM_E_BADARG, "rm_tile_score_from_ray_cost: bad args");
+  rm::k_tile_score<<<grid_for((n_tiles + 3) / 4, kMaxBlocks), 256, 0, (hipStream_t)stream>>>(ray_cost, n_tiles, max_cost, tile_score);
+  return launched("k_tile_score");
 }
 
 int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream) {

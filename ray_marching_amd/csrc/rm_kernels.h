@@ -1145,11 +1145,16 @@ __global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
         const int64_t slot = base + rank;
         int cam = 0, row = 0, col = 0;
         bool take = !has && rank < count;
-        // dealing order (tile_order, here one entry per RAY SLOT = tile * 64 + lane of the tile): the rays that march
-        // longest first, so that what is left when the queues run dry are rays that settle within a few steps -- a
-        // pool cannot refill its idle lanes any more by then
-        const int64_t pos = ((int64_t)q + (slot >> 6) * RM_WORK_QUEUES) * 64 + (slot & 63);
-        if (take) item = a.tile_order ? a.tile_order[pos] : (int)pos;
+        // dealing order (tile_order; with RM_FLAG_ORDER_PER_RAY one entry per RAY SLOT = tile * 64 + lane of the
+        // tile): the rays that march longest first, so that what is left when the queues run dry are rays that settle
+        // within a few steps -- a pool cannot refill its idle lanes any more by then
+        const int64_t tpos = (int64_t)q + (slot >> 6) * RM_WORK_QUEUES;        // dealing position of the tile
+        const int64_t pos = tpos * 64 + (slot & 63);                            // ... of the ray slot
+        if (take) {
+          if (!a.tile_order) item = (int)pos;
+          else if (a.flags & RM_FLAG_ORDER_PER_RAY) item = a.tile_order[pos];
+          else item = a.tile_order[tpos] * 64 + (int)(slot & 63);
+        }
         take = take && ray_of_tile_lane(a, item >> 6, item & 63, cam, row, col);
         if (take) {
           li = ((int64_t)cam * rows + row) * W + col;
@@ -1253,6 +1258,26 @@ __global__ void __launch_bounds__(1024) k_tile_order(const int32_t* __restrict__
   for (int i = lo; i < hi; ++i) {
     const int b = bin_of(cost[i]);
     order[s_hist[b * nt + t]++] = i;
+  }
+}
+
+// Dealing score of a tile from the per-ray step counts k_march_regen recorded (cost[tile * 64 + lane]): which rays
+// march long is noise from one pose to the next (whether an iterate falls into a short exact cycle), how MANY of a
+// tile's rays do is not.  Tiles with long rays (>= 3/4 of the steps) come first, most of them first -- classes
+// 31 .. 16 -- then the tiles without by their longest ray -- classes 15 .. 0.  One wave per tile.
+__global__ void __launch_bounds__(256) k_tile_score(const int32_t* __restrict__ ray_cost, int64_t n_tiles, int max_cost,
+                                                    int32_t* __restrict__ score) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
+    const int c = ray_cost[tile * 64 + lane];
+    const int n_long = __popcll(__ballot(4 * (long long)c >= 3 * (long long)max_cost && c > 0));
+    int mx = c;
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
+    mx = mx < 0 ? 0 : (mx > max_cost ? max_cost : mx);
+    const int by_long = 16 + ((n_long - 1) >> 2);
+    const int by_max = (int)(((long long)mx * 16) / (max_cost + 1));
+    if (lane == 0) score[tile] = n_long ? (by_long > 31 ? 31 : by_long) : by_max;
   }
 }
 

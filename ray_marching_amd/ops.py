@@ -59,9 +59,11 @@ def live_params(cs: CompiledScene, device, *inputs):
     return None
 
 
-def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False, regen: bool = False) -> int:
+def default_flags(early_out: bool = True, tile8x8: bool = False, dynamic_tiles: bool = False, regen: bool = False,
+                  order_per_ray: bool = False) -> int:
     return ((_abi.FLAG_EARLY_OUT if early_out else 0) | (_abi.FLAG_TILE8X8 if tile8x8 else 0) |
-            (_abi.FLAG_DYNAMIC_TILES if dynamic_tiles else 0) | (_abi.FLAG_REGEN if regen else 0))
+            (_abi.FLAG_DYNAMIC_TILES if dynamic_tiles else 0) | (_abi.FLAG_REGEN if regen else 0) |
+            (_abi.FLAG_ORDER_PER_RAY if (regen and order_per_ray) else 0))
 
 
 def regen_applies(flags: int, steps: int, record: bool) -> bool:
@@ -341,7 +343,7 @@ class Render(torch.autograd.Function):
     @staticmethod
     def run(ctx, needs_input_grad, params, orientation, translation, cs: CompiledScene, ray_positions,
             ray_directions, tetra, cmap, mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax,
-            precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None, leaves=()):
+            precision: str = "exact", image_dtype=None, tile_order=None, tile_cost=None, leaves=(), event_sink=None):
         """Body of the forward pass.  ``ctx`` is None for inference frames, which skip the autograd
         machinery altogether (render_frame below)."""
         _require_device(ray_positions, "camera buffers")
@@ -372,7 +374,7 @@ class Render(torch.autograd.Function):
             first_pass = image if image_dtype == torch.float32 else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
         regen = regen_applies(flags, steps, record)
         if not regen:
-            flags &= ~_abi.FLAG_REGEN
+            flags &= ~(_abi.FLAG_REGEN | _abi.FLAG_ORDER_PER_RAY)
         # training: saved for the reverse sweep; ray regeneration: where the march kernel leaves the final iterates
         p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if (record or regen) else None
         traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
@@ -389,7 +391,7 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(rp, rd)
             _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
-            sink = kernel_event_sink
+            sink = event_sink if event_sink is not None else kernel_event_sink
             if sink is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -492,9 +494,11 @@ _NO_GRAD = (False,) * 3
 
 def render_frame(params, orientation, translation, cs: CompiledScene, ray_positions, ray_directions, tetra, cmap,
                  mode: int, degree: int, steps: int, rows, flags: int, allreduce_minmax, precision: str = "exact",
-                 image_dtype=None, tile_order=None, tile_cost=None, leaves=()):
+                 image_dtype=None, tile_order=None, tile_cost=None, leaves=(), event_sink=None):
     """One frame.  Goes through autograd only when something can receive a gradient; an inference frame
-    calls the launch code directly (autograd.Function.apply costs ~20 us per call even under no_grad)."""
+    calls the launch code directly (autograd.Function.apply costs ~20 us per call even under no_grad).
+    ``event_sink`` (inference frames): a list that receives a (start, end) pair of timing events recorded on the
+    launch stream immediately around rm_render_forward."""
     if torch.is_grad_enabled() and ((params is not None and params.requires_grad) or orientation.requires_grad
                                     or translation.requires_grad or any(p.requires_grad for p in leaves)):
         return Render.apply(params, orientation, translation, cs, ray_positions, ray_directions, tetra, cmap, mode,
@@ -502,4 +506,4 @@ def render_frame(params, orientation, translation, cs: CompiledScene, ray_positi
                             *leaves)
     return Render.run(None, _NO_GRAD, params, orientation, translation, cs, ray_positions, ray_directions, tetra,
                       cmap, mode, degree, steps, rows, flags, allreduce_minmax, precision, image_dtype, tile_order,
-                      tile_cost)
+                      tile_cost, (), event_sink)

@@ -1,0 +1,172 @@
+"""Ray regeneration (RM_FLAG_REGEN, include/rm_abi.h): the pool kernels must render the SAME image as the tile
+kernel, bit for bit, whatever the dealing order -- and the tile kernel is what tests/test_gpu_parity.py pins to
+the oracle.  One direct oracle comparison is kept here as well."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import sdf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _same_bits(a, b):
+    a, b = a.contiguous(), b.contiguous()
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    iv = {2: torch.int16, 4: torch.int32, 8: torch.int64}[a.element_size()]
+    return bool(torch.equal(a.view(iv), b.view(iv)))
+
+
+def _poses(n, z, seed):
+    gen = torch.Generator().manual_seed(seed)
+    q = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0, 0.0]]) + 0.1 * torch.randn(n, 4, generator=gen), dim=-1)
+    t = torch.tensor([[0.0, 0.0, z]]) + 0.2 * torch.randn(n, 3, generator=gen)
+    return q.to(DEV), t.to(DEV)
+
+
+@pytest.mark.parametrize("per_ray", [False, True])
+def test_regen_equals_tile_kernel_every_mode_orders_and_overhanging_tiles(per_ray):
+    """Two cameras, a frame whose size is no multiple of the 8x8 tile, all eight shaders; frame 1 is dealt in natural
+    order and records the ray costs, frames 2 and 3 are dealt by the tile scores / per-ray order made of them."""
+    n, h, w, steps = 2, 516, 523, 48
+    tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, n=n, regen=False, adaptive_order=0)
+    pool = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, n=n, regen=True, order_per_ray=per_ray, adaptive_order=2)
+    for z in (-3.0, 1.0):
+        q, t = _poses(n, z, 3)
+        for mode in range(8):
+            if mode == 3:
+                continue            # the reference's vignette shader only broadcasts for one camera (shader.py:64)
+            with torch.no_grad():
+                want = tile(q, t, mode, 2, steps)
+                for frame in range(3):
+                    got = pool(q, t, mode, 2, steps)
+                    assert _same_bits(got, want), (z, mode, frame)
+    st = [s for s in pool._order_state.values() if s.get("T")]
+    assert st and all(s["valid"] for s in st) and st[0]["order"].numel() == (st[0]["T"] * (64 if per_ray else 1))
+    # the order in use is a permutation
+    o = st[0]["order"].long()
+    assert int(o.min()) == 0 and int(o.max()) == o.numel() - 1 and o.unique().numel() == o.numel()
+
+
+def test_regen_against_the_oracle():
+    n, h, w, steps = 1, 40, 56, 32
+    spec = O.scene_test2()
+    loop = H.make_loop(H.spec_to_module(spec), h, w, n=n, regen=True)
+    bufs = O.camera_buffers(n, w, h, H.PX * h, H.PX * w, H.PX * h)
+    q, t = _poses(n, 1.0, 11)
+    for mode in (0, 1, 4, 5, 6):
+        with torch.no_grad(), O.math_mode("restated"):
+            want = O.render(spec, bufs, q.cpu(), t.cpu(), mode, 2, steps, H.EPS, cmap=loop.shader.cyclic_cmap.cpu())
+            got = loop(q, t, mode, 2, steps)
+        worst, _ = H.report(f"regen mode {mode}", got, want)
+        assert worst <= (0.0 if mode != 6 else 1.2e-7), (mode, worst)
+
+
+def test_regen_fp16_module_row_band_and_fallbacks():
+    n, h, w = 1, 300, 410
+    spec = O.scene_test2()
+    tile = H.make_loop(H.spec_to_module(spec), h, w, n=n, regen=False, adaptive_order=0).to(torch.float16)
+    pool = H.make_loop(H.spec_to_module(spec), h, w, n=n, regen=True).to(torch.float16)
+    q, t = _poses(n, 1.0, 5)
+    with torch.no_grad():
+        for mode in (0, 2, 7):
+            assert _same_bits(pool(q.half(), t.half(), mode, 1, 64), tile(q.half(), t.half(), mode, 1, 64)), mode
+        # a row band, as a rank of a row-tiled render asks for
+        assert _same_bits(pool(q.half(), t.half(), 4, 1, 64, rows=(37, 203)), tile(q.half(), t.half(), 4, 1, 64, rows=(37, 203)))
+        # step counts the pools do not take (not a multiple of 4) fall back to the tile kernel
+        assert _same_bits(pool(q.half(), t.half(), 4, 1, 30), tile(q.half(), t.half(), 4, 1, 30))
+        assert _same_bits(pool(q.half(), t.half(), 4, 1, 0), tile(q.half(), t.half(), 4, 1, 0))
+    # a training frame records a trajectory: tile kernel, gradients as ever
+    pool32 = H.make_loop(H.spec_to_module(spec), 64, 64, regen=True)
+    img = pool32(*_poses(1, -3.0, 1), 0, 1, 32)
+    img.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pool32.scene.parameters())
+
+
+def test_regen_flag_is_refused_without_its_buffers():
+    from ray_marching_amd import _abi, ops
+    from ray_marching_amd.compiler import compiled_for
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), 64, 64)
+    cs = compiled_for(loop.scene)
+    rp, rd = loop.camera.ray_positions, loop.camera.ray_directions
+    q, t = _poses(1, -3.0, 1)
+    s, keep = cs.scene_struct(None, rp.device)
+    cam = ops.camera_struct(rp, rd)
+    image = torch.empty(1, 64, 64, 3, device=DEV)
+    work = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=DEV)
+    flags = ops.default_flags(True, True, True, True)
+    rc = _abi.lib.rm_render_forward(s, cam, loop.normals.tetra(), _abi.ptr(q), _abi.ptr(t), _abi.ptr(image), _abi.dtype_code(torch.float32),
+                                    None, None, None, None, _abi.ptr(work), None, 0, 0, 4, 1, 32, 0, 64, flags, None, None, None, 0,
+                                    _abi.current_stream(rp.device))
+    assert rc == -1 and b"RM_FLAG_REGEN" in _abi.lib.rm_last_error()
+    torch.cuda.synchronize()
+
+
+def test_order_sort_and_tile_scores_against_torch():
+    """rm_tile_order_from_cost, one-block and multi-block path: the stable sort by descending cost class;
+    rm_tile_score_from_ray_cost: classes 16..31 by the number of long rays, 0..15 by the longest ray."""
+    from ray_marching_amd import _abi
+    gen = torch.Generator().manual_seed(7)
+    stream = _abi.current_stream(torch.device(DEV))
+    for n, top in ((5000, 128), (131072, 31), (131073, 128), (2_073_600, 128), (777_777, 255)):
+        cost = torch.randint(0, top + 1, (n,), generator=gen, dtype=torch.int32)
+        cost[torch.rand(n, generator=gen) < 0.3] = top                    # a big class, like the rays that never settle
+        cost_d = cost.to(DEV)
+        order = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=DEV)
+        _abi.check(_abi.lib.rm_tile_order_from_cost(_abi.ptr(cost_d), n, top, _abi.ptr(order), _abi.ptr(scratch), stream), "order")
+        cls = 31 - (cost.long() * 32) // (top + 1)
+        want = torch.sort(cls, stable=True).indices
+        assert torch.equal(order.cpu().long(), want), (n, top)
+    # more items than one block sorts, no scratch buffer: refused
+    rc = _abi.lib.rm_tile_order_from_cost(_abi.ptr(cost_d), 777_777, 255, _abi.ptr(order), None, stream)
+    assert rc == -1 and b"scratch" in _abi.lib.rm_last_error()
+    T, S = 3000, 128
+    ray = torch.randint(0, 60, (T, 64), generator=gen, dtype=torch.int32)
+    for i in range(0, T, 3):                                               # every third tile gets some long rays
+        k = int(torch.randint(1, 65, (1,), generator=gen))
+        ray[i, :k] = torch.randint(96, S + 1, (k,), generator=gen, dtype=torch.int32)
+    score = torch.empty(T, dtype=torch.int32, device=DEV)
+    ray_d = ray.to(DEV)
+    _abi.check(_abi.lib.rm_tile_score_from_ray_cost(_abi.ptr(ray_d), T, S, _abi.ptr(score), stream), "score")
+    n_long = (ray >= 96).sum(dim=1)
+    want = torch.where(n_long > 0, torch.clamp(16 + (n_long - 1) // 4, max=31), (ray.max(dim=1).values.long() * 16) // (S + 1))
+    assert torch.equal(score.cpu().long(), want)
+
+
+def test_captured_frame_with_regen_follows_the_camera():
+    """regen=True under HIP-graph replay: two graphs (plain / recording + order renewal) share the static buffers."""
+    n, h, w, steps = 1, 520, 528, 32
+    tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0)
+    pool = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=True, adaptive_order=3)
+    frame = pool.capture(4, 1, steps)
+    assert frame.graph_record is not None
+    for i in range(8):
+        q, t = _poses(n, 1.0 - 0.5 * i, 20 + i)
+        with torch.no_grad():
+            assert _same_bits(frame(q, t), tile(q, t, 4, 1, steps)), i
+
+
+def test_auto_mode_takes_the_faster_kernel():
+    """regen="auto" (the default) at 1080p: the pools inside the torus (0,0,1), the tile kernel in front of the scene
+    (0,0,-3): 404 vs 317 us and 214 vs 245 us per frame (profiles/regen_probe.py)."""
+    h, w, steps = 1080, 1920, 128
+    tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV)
+    for z, want_regen in ((1.0, True), (-3.0, False)):
+        auto = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)
+        assert auto.regen == "auto"
+        t = torch.tensor([[0.0, 0.0, z]], device=DEV)
+        with torch.no_grad():
+            want = tile(q, t, 4, 1, steps)
+            for i in range(70):
+                got = auto(q, t, 4, 1, steps)
+                if i % 16 < 3:
+                    assert _same_bits(got, want), (z, i)
+                    torch.cuda.synchronize()
+        (st,) = auto._choice_state.values()
+        assert st["regen"] is want_regen, (z, st)

@@ -68,6 +68,17 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert render(0, image_dtype=2) == -1 and b"F64" in lib.rm_last_error()   # float64 image only for modes 6, 7
     assert render(6) == -1 and b"colormap" in lib.rm_last_error()
     assert render(6, cmap=16, cmap_dtype=7) == -1
+
+    def regen(steps=8, p_final=16, minmax=16, flags=1 | 2 | 4 | 8, traj=None):
+        return lib.rm_render_forward(ok, cam, tet, 16, 16, 16, 0, None, p_final, traj, None, minmax, None, 0, 0, 0, 1, steps,
+                                     0, 4, flags, None, None, None, 0, None)
+
+    # ray regeneration states its requirements instead of doing something else
+    for bad in (dict(p_final=None), dict(minmax=None), dict(steps=6), dict(flags=2 | 4 | 8), dict(flags=1 | 4 | 8), dict(traj=16)):
+        assert regen(**bad) == -1 and b"RM_FLAG_REGEN" in lib.rm_last_error(), bad
+    assert lib.rm_tile_order_from_cost(None, 10, 8, None, None, None) == -1
+    assert lib.rm_tile_order_from_cost(16, 1 << 20, 8, 16, None, None) == -1 and b"scratch" in lib.rm_last_error()
+    assert lib.rm_tile_score_from_ray_cost(16, 0, 8, 16, None) == -1
     cam64 = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4, dtype=2)
     assert render(0, cam_=cam64) == -1 and b"camera dtype" in lib.rm_last_error()
     assert lib.rm_wave_tiles(1, 1080, 1920, _abi.FLAG_TILE8X8) == 135 * 240
