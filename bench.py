@@ -138,10 +138,20 @@ def pipelined_probe(loop, q, t, rows, dev, rays_per_frame, frames=40, nstreams=2
             "value": rays_per_frame * frames / dt / 1e6, "unit": "Mrays/s"}
 
 
-def frame_rate(loop, q, t, rows, frames=20, modes=MODES, steps=STEPS_MARCH):
+def kernel_in_use(loop):
+    """Which frame kernel RenderLoop(regen='auto') settled on for the launches timed last (None: not applicable)."""
+    if loop.regen != "auto":
+        return "k_march_regen + k_render_finish" if loop.regen else "k_render_fwd"
+    states = list(loop._choice_state.values())
+    if not states:
+        return "k_render_fwd"
+    return "k_march_regen + k_render_finish" if states[-1]["regen"] else "k_render_fwd"
+
+
+def frame_rate(loop, q, t, rows, frames=20, modes=MODES, steps=STEPS_MARCH, warm=4):
     """Serial, one-stream frame time of `loop` at pose (q, t): ms per frame."""
     with torch.no_grad():
-        for i in range(4):
+        for i in range(warm):
             loop(q, t, modes[i % len(modes)], 1, steps, rows=rows)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -165,9 +175,10 @@ def config3_probe(dev):
            "bytes_per_ray": 18}
     for z in (-3.0, 1.0):
         t = torch.tensor([[0.0, 0.0, z]], device=dev, dtype=torch.float16)
-        ms = frame_rate(loop, q, t, None, frames=10, steps=steps)
+        ms = frame_rate(loop, q, t, None, frames=16, steps=steps, warm=36)
         out[f"camera_z{z:+g}"] = {"ms_per_frame": ms, "value": h * w / ms / 1e3, "unit": "Mrays/s",
-                                  "hbm_frac": h * w * 18 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  "hbm_frac": h * w * 18 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_in_use(loop)}
+        loop._choice_state.clear()
     return out
 
 
@@ -393,11 +404,13 @@ def main():
         band = (rank * H_TILE, (rank + 1) * H_TILE)
         focal, sensor_h = PX * H_TILE, PX * h_total
     # every rank holds only ITS band of the camera buffers (RenderLoop(rows=...))
-    loop = RenderLoop(make_scene(), num_cameras=1, px_width=width, px_height=h_total, focal_length=focal,
-                      sensor_width=PX * width, sensor_height=sensor_h, normals_eps=EPS,
-                      early_out=not args.no_early_out, tile8x8=not args.linear_waves,
-                      dynamic_tiles=not args.static_tiles, precision=args.precision,
-                      rows=None if world == 1 else band).to(dev)
+    def make_loop(**kw):
+        return RenderLoop(make_scene(), num_cameras=1, px_width=width, px_height=h_total, focal_length=focal,
+                          sensor_width=PX * width, sensor_height=sensor_h, normals_eps=EPS,
+                          early_out=not args.no_early_out, tile8x8=not args.linear_waves,
+                          dynamic_tiles=not args.static_tiles, precision=args.precision,
+                          rows=None if world == 1 else band, **kw).to(dev)
+    loop = make_loop()
     specialised = compiled_for(loop.scene).specialised
     rows = None if world > 1 else (band if not config5 else None)
     band_rows = band[1] - band[0]
@@ -478,7 +491,7 @@ def main():
             log(f"roofline.traffic: {why}")
         roof = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_render_fwd", "kernel_ms": per_launch_ms,
+                "kernel": kernel_in_use(loop), "kernel_ms": per_launch_ms,
                 "algorithmic_bytes_per_launch": launch_rays * BYTES_PER_RAY,
                 "binding": "fp32-valu issue (SURVEY D8: ~300 flop/B, the fused frame cannot be HBM bound)"}
         if not config5:
@@ -527,12 +540,27 @@ def main():
             # SURVEY 8(d) names two cameras for config 2, and they are equals here: (0,0,-3), outside the torus,
             # and the reference's own start pose (0,0,1) (main.py:46), inside the torus tube, where more rays
             # never settle.  `value` is the pose of --camera-z (default -3); both are measured the same way.
+            # RenderLoop's default regen="auto" times the tile kernel against the ray-regeneration kernels now and then
+            # and uses the faster one; the fixed choices are listed beside it.  "per-ray order" deals the rays by the
+            # step counts of the previous IDENTICAL frame: right for a viewer that re-renders an unchanged pose, and for
+            # this fixed-pose loop -- which rays march long changes with the least camera move, so it is NOT the default.
             poses = []
+            variants = {"tile kernel": dict(regen=False), "regeneration, tile-score order": dict(regen=True),
+                        "regeneration, per-ray order (unchanged pose only)": dict(regen=True, order_per_ray=True)}
             for z in (-3.0, 1.0):
                 tz = torch.tensor([[0.0, 0.0, z]], device=dev)
-                ms = frame_rate(loop, q, tz, rows)
-                poses.append({"camera": [0.0, 0.0, z], "ms_per_frame": ms, "value": rays_per_frame / ms / 1e3, "unit": "Mrays/s",
-                              "note": "the reference's default pose (main.py:46)" if z == 1.0 else "outside the torus, every ray hits"})
+                auto = make_loop()
+                ms = frame_rate(auto, q, tz, rows, frames=32, warm=48)
+                entry_ = {"camera": [0.0, 0.0, z], "ms_per_frame": ms, "value": rays_per_frame / ms / 1e3, "unit": "Mrays/s",
+                          "kernel": kernel_in_use(auto), "fixed_choices": {},
+                          "note": "the reference's default pose (main.py:46)" if z == 1.0 else "outside the torus, every ray hits"}
+                del auto
+                for name, kw in variants.items():
+                    lv = make_loop(**kw)
+                    mv = frame_rate(lv, q, tz, rows, frames=32, warm=20)
+                    entry_["fixed_choices"][name] = {"ms_per_frame": mv, "value": rays_per_frame / mv / 1e3}
+                    del lv
+                poses.append(entry_)
             out["poses"] = poses
             out["pipelined"] = pipelined_probe(loop, q, t, rows, dev, rays_per_frame)
             if not args.skip_config3:

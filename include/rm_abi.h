@@ -243,9 +243,9 @@ int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t 
 
 /* tile_order for the NEXT frame from this frame's tile_cost (values 0 .. max_cost = the step count): items by
  * decreasing cost class (32 classes), natural order inside a class (stable counting sort).  Worth it when consecutive
- * frames are coherent (an interactive camera).  Up to RM_ORDER_ONE_BLOCK items one block sorts them; beyond (the
- * per-ray orders of RM_FLAG_REGEN) two multi-block kernels do, through `scratch` = device int32[RM_ORDER_SCRATCH_INTS]
- * (NULL allowed for the small case). */
+ * frames are coherent (an interactive camera).  `scratch` = device int32[RM_ORDER_SCRATCH_INTS] lets several blocks
+ * share the work (1080p tiles: 96 us with one block, ~10 us with 8); NULL is allowed up to RM_ORDER_ONE_BLOCK items,
+ * which one block then sorts alone. */
 int rm_tile_score_from_ray_cost(const int32_t* ray_cost /*[64 * n_tiles]*/, int64_t n_tiles, int32_t max_cost,
                                 int32_t* tile_score /*[n_tiles], values 0..31: sort with max_cost = 31*/, void* stream);
 #define RM_ORDER_ONE_BLOCK 131072

@@ -218,13 +218,14 @@ class RenderLoop(nn.Module):
         of a cycle runs the kernel NOT in use (and renews its dealing order, so that it is measured with an order as old
         as it would be in use), the second one the kernel in use, both between timing events on the launch stream that
         are looked at -- without waiting -- by later frames; the other kernel takes over when it was more than 3 %
-        faster.  A probe costs one frame in sixteen the difference between the two kernels."""
+        faster, and is only looked at every fourth cycle after it was more than 10 % slower.  A probe costs one frame
+        in 16 (64) the difference between the two kernels plus the order renewal: ~0.5 % of the 1080p headline."""
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
         key = (r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream)
         st = self._choice_state.get(key)
         if st is None:
-            st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}}
+            st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}, "skip": 0}
         for name in list(st["pending"]):
             pair = st["pending"][name]
             if pair and pair[0][1].query():
@@ -233,14 +234,21 @@ class RenderLoop(nn.Module):
         if len(st["ms"]) == 2:
             if st["ms"]["other"] < 0.97 * st["ms"]["used"]:
                 st["regen"] = not st["regen"]
+                st["skip"] = 0
+            else:       # clearly slower: look again only every fourth cycle
+                st["skip"] = 3 if st["ms"]["other"] > 1.10 * st["ms"]["used"] else 0
             st["ms"] = {}
         cycle = self.adaptive_order if self.adaptive_order > 0 else 16
         phase = st["n"] % cycle
         st["n"] += 1
         if cycle > 1 and phase == 0:
-            st["ms"], st["pending"] = {}, {"other": []}
-            return (not st["regen"]), True, st["pending"]["other"]
-        if cycle > 1 and phase == 1:
+            st["ms"], st["pending"] = {}, {}
+            if st["skip"] > 0:
+                st["skip"] -= 1
+            else:
+                st["pending"]["other"] = []
+                return (not st["regen"]), True, st["pending"]["other"]
+        if cycle > 1 and phase == 1 and ("other" in st["pending"] or "other" in st["ms"]):
             st["pending"]["used"] = []
             return st["regen"], False, st["pending"]["used"]
         return st["regen"], False, None
@@ -294,8 +302,7 @@ class RenderLoop(nn.Module):
         return {"T": T, "n_order": n_order, "cost": torch.empty(n_cost, dtype=torch.int32, device=dev),
                 "order": torch.empty(n_order, dtype=torch.int32, device=dev), "frame": 0, "valid": False,
                 "score": torch.empty(T, dtype=torch.int32, device=dev) if (regen and not per_ray) else None,
-                "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)
-                if n_order > _abi.ORDER_ONE_BLOCK else None}
+                "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)}
 
     @staticmethod
     def _renew_order(st, steps: int, dev):

@@ -555,25 +555,24 @@ int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t m
     return fail(RM_E_BADARG, "rm_tile_order_from_cost: bad args");
   if (n_tiles > RM_ORDER_ONE_BLOCK && !scratch)
     return fail(RM_E_BADARG, "rm_tile_order_from_cost: more than %d items need the scratch buffer", RM_ORDER_ONE_BLOCK);
-  const size_t lds = (32 * 1024 + 32) * sizeof(int);      // 128 KiB of gfx950's 160 KiB
+  const size_t lds = (32 * 1024 + 64) * sizeof(int);      // 128 KiB of gfx950's 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_tile_order),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_order_scatter),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_order_scatter),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute(k_tile_order): %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute(k_order_scatter): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  if (n_tiles <= RM_ORDER_ONE_BLOCK) {
-    rm::k_tile_order<<<1, 1024, lds, (hipStream_t)stream>>>(tile_cost, (int)n_tiles, max_cost, tile_order);
-    return launched("k_tile_order");
+  // one block up to 4096 items (or without scratch), else ~4096 items per block: 1080p tiles 8 blocks, rays 256
+  int blocks = 1;
+  if (scratch && n_tiles > 4096) {
+    blocks = (int)((n_tiles + 4095) / 4096);
+    if (blocks > RM_ORDER_SCRATCH_INTS / 32) blocks = RM_ORDER_SCRATCH_INTS / 32;
   }
-  int blocks = (int)((n_tiles + 16383) / 16384);
-  if (blocks > RM_ORDER_SCRATCH_INTS / 32) blocks = RM_ORDER_SCRATCH_INTS / 32;
-  rm::k_order_count<<<blocks, 1024, 0, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch);
-  if (int e = launched("k_order_count")) return e;
+  if (blocks > 1) {
+    rm::k_order_count<<<blocks, 1024, 0, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch);
+    if (int e = launched("k_order_count")) return e;
+  }
   rm::k_order_scatter<<<blocks, 1024, lds, (hipStream_t)stream>>>(tile_cost, n_tiles, max_cost, scratch, tile_order);
   return launched("k_order_scatter");
 }

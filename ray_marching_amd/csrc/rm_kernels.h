@@ -1219,48 +1219,6 @@ __global__ void __launch_bounds__(256) k_render_finish(RenderArgs a) {
     fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
 }
 
-// Longest-first dealing order from the previous frame's per-tile step counts: STABLE counting sort by descending
-// cost class (32 classes; one block, every thread owns a contiguous run of tiles and its own 32 counters in LDS), so
-// tiles of one class keep their natural, spatially coherent order (a scatter through atomics shuffled them and cost
-// the headline frame 5 %).  Any permutation renders the same image.
-__global__ void __launch_bounds__(1024) k_tile_order(const int32_t* __restrict__ cost, int n_tiles, int max_cost,
-                                                     int32_t* __restrict__ order) {
-  constexpr int kBins = 32;
-  extern __shared__ int s_hist[];                         // [kBins][blockDim.x]: bin-major, so the scan below is linear
-  const int nt = blockDim.x, t = threadIdx.x;
-  const int chunk = (n_tiles + nt - 1) / nt;
-  const int lo = t * chunk, hi = (lo + chunk < n_tiles) ? lo + chunk : n_tiles;
-  auto bin_of = [&](int c) {
-    c = c < 0 ? 0 : (c > max_cost ? max_cost : c);
-    return (kBins - 1) - (int)(((long long)c * kBins) / (max_cost + 1));    // bin 0 = the most expensive class
-  };
-  for (int b = 0; b < kBins; ++b) s_hist[b * nt + t] = 0;
-  for (int i = lo; i < hi; ++i) s_hist[bin_of(cost[i]) * nt + t] += 1;
-  __syncthreads();
-  // exclusive scan over (bin, thread) in that order: 32 * 1024 entries, by one wave, 512 entries per lane
-  if (t < 64) {
-    const int per = (kBins * nt) / 64;
-    int local = 0;
-    for (int k = 0; k < per; ++k) local += s_hist[t * per + k];
-    int incl = local;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (t >= o) incl += up;
-    }
-    int run = incl - local;
-    for (int k = 0; k < per; ++k) {
-      const int h = s_hist[t * per + k];
-      s_hist[t * per + k] = run;
-      run += h;
-    }
-  }
-  __syncthreads();
-  for (int i = lo; i < hi; ++i) {
-    const int b = bin_of(cost[i]);
-    order[s_hist[b * nt + t]++] = i;
-  }
-}
-
 // Dealing score of a tile from the per-ray step counts k_march_regen recorded (cost[tile * 64 + lane]): which rays
 // march long is noise from one pose to the next (whether an iterate falls into a short exact cycle), how MANY of a
 // tile's rays do is not.  Tiles with long rays (>= 3/4 of the steps) come first, most of them first -- classes
@@ -1281,10 +1239,14 @@ __global__ void __launch_bounds__(256) k_tile_score(const int32_t* __restrict__ 
   }
 }
 
-// The same stable counting sort for item counts one block cannot hold (the per-ray orders of RM_FLAG_REGEN: 2 M items
-// for a 1080p frame): block b owns a contiguous chunk, thread t a contiguous run of it.  k_order_count leaves the
-// per-(block, class) totals in `counts`; k_order_scatter recounts, scans (class, thread) inside the block like
-// k_tile_order and adds the start of its (class, block) cell in the global class-major, block-minor layout.
+// Longest-first dealing order from the previous frame's step counts: STABLE counting sort by descending cost class
+// (32 classes), so items of one class keep their natural, spatially coherent order (a scatter through atomics shuffled
+// the tiles and cost the headline frame 5 %).  Any permutation renders the same image.
+//
+// Block b owns a contiguous chunk of the items, thread t a contiguous run of it, with its own 32 counters in LDS
+// (bin-major [32][1024]).  k_order_count leaves the per-(block, class) totals in `counts`; k_order_scatter recounts,
+// scans every class row over the threads (one wave per row, 16 rows at a time) and adds the start of its
+// (class, block) cell in the global class-major, block-minor layout.  One block needs no `counts`.
 RM_DEV int order_bin(int c, int max_cost) {
   c = c < 0 ? 0 : (c > max_cost ? max_cost : c);
   return 31 - (int)(((long long)c * 32) / (max_cost + 1));                  // bin 0 = the most expensive class
@@ -1317,27 +1279,50 @@ __global__ void __launch_bounds__(1024) k_order_count(const int32_t* __restrict_
   if (t < 32) counts[blockIdx.x * 32 + t] = s_tot[t];
 }
 
+// `counts` may be null when the grid is one block
 __global__ void __launch_bounds__(1024) k_order_scatter(const int32_t* __restrict__ cost, int64_t n, int max_cost,
                                                         const int32_t* __restrict__ counts, int32_t* __restrict__ order) {
   constexpr int kBins = 32;
-  extern __shared__ int s_hist[];                         // [kBins][blockDim.x] + [kBins] cell starts
-  const int nt = blockDim.x, t = threadIdx.x;
-  int* s_base = s_hist + kBins * nt;
+  extern __shared__ int s_hist[];                         // [kBins][blockDim.x], then [kBins] row totals, [kBins] cell starts
+  const int nt = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = nt >> 6;
+  int* s_tot = s_hist + kBins * nt;
+  int* s_base = s_tot + kBins;
   const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
   const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = (b0 + chunk < n) ? b0 + chunk : n;
   const int64_t run = (chunk + nt - 1) / nt;
   const int64_t lo = (b0 + t * run < b1) ? b0 + t * run : b1, hi = (lo + run < b1) ? lo + run : b1;
   for (int b = 0; b < kBins; ++b) s_hist[b * nt + t] = 0;
   for (int64_t i = lo; i < hi; ++i) s_hist[order_bin(cost[i], max_cost) * nt + t] += 1;
+  __syncthreads();
+  // exclusive scan of every class row over the threads: 64 entries at a time (conflict-free), carry in between
+  for (int b = wave; b < kBins; b += nwaves) {
+    int* row = s_hist + b * nt;
+    int carry = 0;
+    for (int k = 0; k < nt; k += 64) {
+      const int v = row[k + lane];
+      int incl = v;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      row[k + lane] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) s_tot[b] = carry;
+  }
+  __syncthreads();
   if (t < 64) {
     // start of cell (class t, this block): all items of more expensive classes, then this class in earlier blocks
     int total = 0, before = 0;
-    if (t < kBins)
-      for (int b = 0; b < (int)gridDim.x; ++b) {
-        const int c = counts[b * 32 + t];
-        total += c;
-        if (b < (int)blockIdx.x) before += c;
-      }
+    if (t < kBins) {
+      if (gridDim.x == 1) total = s_tot[t];
+      else
+        for (int b = 0; b < (int)gridDim.x; ++b) {
+          const int c = counts[b * 32 + t];
+          total += c;
+          if (b < (int)blockIdx.x) before += c;
+        }
+    }
     int incl = total;
     for (int o = 1; o < 64; o <<= 1) {
       const int up = __shfl_up(incl, o, 64);
@@ -1346,34 +1331,9 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const int32_t* __restric
     if (t < kBins) s_base[t] = (incl - total) + before;
   }
   __syncthreads();
-  if (t < 64) {                                           // exclusive scan over (bin, thread), as in k_tile_order
-    const int per = (kBins * nt) / 64;
-    int local = 0;
-    for (int k = 0; k < per; ++k) local += s_hist[t * per + k];
-    int incl = local;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (t >= o) incl += up;
-    }
-    int runsum = incl - local;
-    for (int k = 0; k < per; ++k) {
-      const int h = s_hist[t * per + k];
-      s_hist[t * per + k] = runsum;
-      runsum += h;
-    }
-  }
-  __syncthreads();
-  // block-local position of (bin, thread) minus the block-local start of the bin + the global start of the cell
-  int shift[kBins];
-#pragma unroll
-  for (int b = 0; b < kBins; ++b) shift[b] = s_base[b] - s_hist[b * nt];
-  __syncthreads();
   for (int64_t i = lo; i < hi; ++i) {
     const int b = order_bin(cost[i], max_cost);
-    int sh = 0;
-#pragma unroll
-    for (int k = 0; k < kBins; ++k) sh = (k == b) ? shift[k] : sh;
-    order[sh + s_hist[b * nt + t]++] = (int32_t)i;
+    order[s_base[b] + s_hist[b * nt + t]++] = (int32_t)i;
   }
 }
 
