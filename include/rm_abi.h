@@ -246,8 +246,13 @@ int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t 
  * frames are coherent (an interactive camera).  `scratch` = device int32[RM_ORDER_SCRATCH_INTS] lets several blocks
  * share the work (1080p tiles: 96 us with one block, ~10 us with 8); NULL is allowed up to RM_ORDER_ONE_BLOCK items,
  * which one block then sorts alone. */
-int rm_tile_score_from_ray_cost(const int32_t* ray_cost /*[64 * n_tiles]*/, int64_t n_tiles, int32_t max_cost,
-                                int32_t* tile_score /*[n_tiles], values 0..31: sort with max_cost = 31*/, void* stream);
+/* Tile scores (0..31: sort with max_cost = 31) from the per-ray costs RM_FLAG_REGEN recorded, for frames of
+ * n_tiles = cameras * tiles_x * tiles_y 8x8 tiles: 31..17 tiles with rays that marched >= 3/4 of max_cost steps, by their
+ * number; 16 tiles without, within `reach` tiles of one (where such rays turn up when the camera moves by up to
+ * 8 * reach pixels before the order is renewed); 15..0 the rest by the longest ray in that neighbourhood.
+ * raw: device scratch int32[n_tiles]. */
+int rm_tile_score_from_ray_cost(const int32_t* ray_cost /*[64 * n_tiles]*/, int64_t n_tiles, int32_t tiles_x, int32_t tiles_y,
+                                int32_t reach, int32_t max_cost, int32_t* raw, int32_t* tile_score /*[n_tiles]*/, void* stream);
 #define RM_ORDER_ONE_BLOCK 131072
 #define RM_ORDER_SCRATCH_INTS 8192
 int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_order,

@@ -13,7 +13,7 @@ from ray_marching_amd.scene.scene_registry import make_test_scene2  # noqa: E402
 PX, W, H = 3.45e-6, 1920, 1080
 dev = torch.device("cuda:0")
 loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=H, focal_length=PX * H,
-                  sensor_width=PX * W, sensor_height=PX * H, normals_eps=5e-2).to(dev)
+                  sensor_width=PX * W, sensor_height=PX * H, normals_eps=5e-2, regen=False).to(dev)   # the tile kernel only
 q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
 t = torch.tensor([[0.0, 0.0, -3.0]], device=dev)
 with torch.no_grad():

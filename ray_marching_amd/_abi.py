@@ -78,7 +78,7 @@ _SIGNATURES = {
     "rm_park_floats": (C.c_int64, [C.c_int64]),
     "rm_wave_tiles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_tile_order_from_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P]),
-    "rm_tile_score_from_ray_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
+    "rm_tile_score_from_ray_cost": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),

@@ -211,6 +211,9 @@ class RenderLoop(nn.Module):
     # frames smaller than this never take the regeneration kernels in "auto" mode: a 1080p frame is 6 draws per pool
     # lane, below ~1 M rays the pools hardly refill at all
     REGEN_AUTO_MIN_RAYS = 1 << 20
+    # tiles this close to a tile with long rays are dealt right after those (rm_tile_score_from_ray_cost): covers a
+    # camera that moves by up to 8 pixels per tile of reach before the order is renewed
+    ORDER_REACH_TILES = int(os.environ.get("RM_ORDER_REACH", 2))
 
     def _choose_kernel(self, rp: Tensor, rows, steps: int):
         """regen="auto": (use the regeneration kernels for this frame?, record the dealing order now?, list for the
@@ -301,7 +304,8 @@ class RenderLoop(nn.Module):
         n_order = T * 64 if per_ray else T
         return {"T": T, "n_order": n_order, "cost": torch.empty(n_cost, dtype=torch.int32, device=dev),
                 "order": torch.empty(n_order, dtype=torch.int32, device=dev), "frame": 0, "valid": False,
-                "score": torch.empty(T, dtype=torch.int32, device=dev) if (regen and not per_ray) else None,
+                "score": torch.empty(2 * T, dtype=torch.int32, device=dev) if (regen and not per_ray) else None,
+                "grid": ((w + 7) // 8, (r1 - r0 + 7) // 8),
                 "scratch": torch.empty(_abi.ORDER_SCRATCH_INTS, dtype=torch.int32, device=dev)}
 
     @staticmethod
@@ -311,8 +315,10 @@ class RenderLoop(nn.Module):
             stream = _abi.current_stream(dev)
             src, top = st["cost"], steps
             if st["score"] is not None:
-                _abi.check(ops._lib.rm_tile_score_from_ray_cost(_abi.ptr(st["cost"]), st["T"], steps, _abi.ptr(st["score"]),
-                                                                stream), "rm_tile_score_from_ray_cost")
+                raw = st["score"][st["T"]:]
+                _abi.check(ops._lib.rm_tile_score_from_ray_cost(_abi.ptr(st["cost"]), st["T"], st["grid"][0], st["grid"][1],
+                                                                RenderLoop.ORDER_REACH_TILES, steps, _abi.ptr(raw),
+                                                                _abi.ptr(st["score"]), stream), "rm_tile_score_from_ray_cost")
                 src, top = st["score"], 31
             _abi.check(ops._lib.rm_tile_order_from_cost(_abi.ptr(src), st["n_order"], top, _abi.ptr(st["order"]),
                                                         _abi.ptr(st["scratch"]), stream), "rm_tile_order_from_cost")

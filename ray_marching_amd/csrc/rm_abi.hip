@@ -577,11 +577,16 @@ int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t m
   return launched("k_order_scatter");
 }
 
-int rm_tile_score_from_ray_cost(const int32_t* ray_cost, int64_t n_tiles, int32_t max_cost, int32_t* tile_score, void* stream) {
-  if (!ray_cost || !tile_score || n_tiles <= 0 || n_tiles > 0x1ffffff || max_cost < 0)
+int rm_tile_score_from_ray_cost(const int32_t* ray_cost, int64_t n_tiles, int32_t tiles_x, int32_t tiles_y, int32_t reach,
+                                int32_t max_cost, int32_t* raw, int32_t* tile_score, void* stream) {
+  if (!ray_cost || !tile_score || !raw || n_tiles <= 0 || n_tiles > 0x1ffffff || max_cost < 0 || tiles_x <= 0 || tiles_y <= 0 ||
+      n_tiles % ((int64_t)tiles_x * tiles_y) != 0 || reach < 0 || reach > 8)
     return fail(RM_E_BADARG, "rm_tile_score_from_ray_cost: bad args");
-  rm::k_tile_score<<<grid_for((n_tiles + 3) / 4, kMaxBlocks), 256, 0, (hipStream_t)stream>>>(ray_cost, n_tiles, max_cost, tile_score);
-  return launched("k_tile_score");
+  rm::k_tile_score_raw<<<grid_for((n_tiles + 3) / 4, kMaxBlocks), 256, 0, (hipStream_t)stream>>>(ray_cost, n_tiles, max_cost, raw);
+  if (int e = launched("k_tile_score_raw")) return e;
+  rm::k_tile_score_classes<<<grid_for((n_tiles + 255) / 256, kMaxBlocks), 256, 0, (hipStream_t)stream>>>(
+      raw, n_tiles, tiles_x, tiles_y, reach, max_cost, tile_score);
+  return launched("k_tile_score_classes");
 }
 
 int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream) {

@@ -192,6 +192,12 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 // loop would have produced.  With a trajectory being recorded (backward) the same exits are taken and the
 // iterates of steps >= nexec are not stored: the reverse sweep uses p_final for them (exact for a fixed point,
 // an ulp or two off inside a cycle between neighbouring floats -- a VJP argument, tolerance 1e-4).
+#ifndef RM_PRIO_TILE
+#define RM_PRIO_TILE 32           // march step from which a tile's wave runs at raised issue priority (0 = never)
+#endif
+#ifndef RM_PRIO_REGEN
+#define RM_PRIO_REGEN 16          // the same for a pool holding a ray that has marched this long
+#endif
 #ifndef RM_EARLY_DENSE_STEPS
 #define RM_EARLY_DENSE_STEPS 8    // look for cycles after every 2nd step up to here, after every 4th from then on
 #endif                            // (>= 4: the snapshot refreshes at steps 2 and 4 happen inside those looks)
@@ -229,7 +235,15 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
   // drift of p cannot accumulate beyond the slack folded into the bound (derive_constants)
   const float vn = 1.0001f * __builtin_amdgcn_sqrtf(__builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
   float move = __builtin_nanf("");
+#if RM_PRIO_TILE > 0
+  __builtin_amdgcn_s_setprio(0);
+#endif
   for (int i = 0; i < steps; ++i) {
+#if RM_PRIO_TILE > 0
+    // a tile still marching by now is one of those that decide when the launch ends: its wave is issued first from
+    // here on (measured, profiles/regen_probe.py: 32-primitive 8K band 11.45 -> 10.65 ms, 1080p scene 2 208 -> 204 us)
+    if (i == RM_PRIO_TILE) __builtin_amdgcn_s_setprio(3);
+#endif
     if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
     float f = scene.eval_near(p, (i & 15) ? move : __builtin_nanf(""));
     move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
@@ -1174,6 +1188,12 @@ __global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
       continue;                                   // (a ray of zero steps retires at once; an empty draw tries again)
     }
     const bool act = has && k < stop;
+#if RM_PRIO_REGEN > 0
+    // rays that have marched long are the critical path of the launch (nothing can refill their lanes once the queues
+    // are dry): pools holding one are issued first (32-primitive 8K band 11.08 -> 10.42 ms; 1080p scene 2 unchanged)
+    if (__any(act && k >= RM_PRIO_REGEN)) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     if (act) {
       V3 prev = p;
       for (int j = 0; j < 4; ++j) {
@@ -1221,10 +1241,14 @@ __global__ void __launch_bounds__(256) k_render_finish(RenderArgs a) {
 
 // Dealing score of a tile from the per-ray step counts k_march_regen recorded (cost[tile * 64 + lane]): which rays
 // march long is noise from one pose to the next (whether an iterate falls into a short exact cycle), how MANY of a
-// tile's rays do is not.  Tiles with long rays (>= 3/4 of the steps) come first, most of them first -- classes
-// 31 .. 16 -- then the tiles without by their longest ray -- classes 15 .. 0.  One wave per tile.
-__global__ void __launch_bounds__(256) k_tile_score(const int32_t* __restrict__ ray_cost, int64_t n_tiles, int max_cost,
-                                                    int32_t* __restrict__ score) {
+// tile's rays do is not (correlation 0.96 - 0.999 across a one-pixel camera move, profiles/regen_costmap.py).
+// Tiles with long rays (>= 3/4 of the steps) come first, most of them first -- classes 31 .. 17; then, class 16,
+// the tiles WITHOUT long rays within `reach` tiles of one: when the camera moves by up to 8 * reach pixels until the
+// order is renewed these are where long rays turn up, and a long ray dealt at the very end of the order is the
+// worst case (measured: 2 % of such tiles cost 13 % of the frame); then the rest by the longest ray in their
+// neighbourhood -- classes 15 .. 0.  Pass 1: one wave per tile, raw = long rays << 16 | longest ray.
+__global__ void __launch_bounds__(256) k_tile_score_raw(const int32_t* __restrict__ ray_cost, int64_t n_tiles, int max_cost,
+                                                        int32_t* __restrict__ raw) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
@@ -1233,9 +1257,31 @@ __global__ void __launch_bounds__(256) k_tile_score(const int32_t* __restrict__ 
     int mx = c;
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
     mx = mx < 0 ? 0 : (mx > max_cost ? max_cost : mx);
-    const int by_long = 16 + ((n_long - 1) >> 2);
-    const int by_max = (int)(((long long)mx * 16) / (max_cost + 1));
-    if (lane == 0) score[tile] = n_long ? (by_long > 31 ? 31 : by_long) : by_max;
+    if (mx > 0xffff) mx = 0xffff;
+    if (lane == 0) raw[tile] = (n_long << 16) | mx;
+  }
+}
+
+// Pass 2: classes from the raw values of the (2 reach + 1)^2 neighbourhood inside the tile grid of the camera
+__global__ void __launch_bounds__(256) k_tile_score_classes(const int32_t* __restrict__ raw, int64_t n_tiles, int tiles_x,
+                                                            int tiles_y, int reach, int max_cost, int32_t* __restrict__ score) {
+  const int64_t per_cam = (int64_t)tiles_x * tiles_y;
+  for (int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cam0 = (tile / per_cam) * per_cam;
+    const int ty = (int)((tile - cam0) / tiles_x), tx = (int)((tile - cam0) - (int64_t)ty * tiles_x);
+    const int own = raw[tile];
+    int near_long = 0, near_max = own & 0xffff;
+    for (int dy = -reach; dy <= reach; ++dy)
+      for (int dx = -reach; dx <= reach; ++dx) {
+        const int y = ty + dy, x = tx + dx;
+        if (y < 0 || y >= tiles_y || x < 0 || x >= tiles_x) continue;
+        const int r = raw[cam0 + (int64_t)y * tiles_x + x];
+        near_long |= r >> 16;
+        near_max = (r & 0xffff) > near_max ? (r & 0xffff) : near_max;
+      }
+    const int n_long = own >> 16;
+    const int mx = near_max > max_cost ? max_cost : near_max;
+    score[tile] = n_long ? 17 + ((n_long - 1) * 15) / 64 : (near_long ? 16 : (int)(((long long)mx * 16) / (max_cost + 1)));
   }
 }
 

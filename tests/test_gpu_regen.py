@@ -125,17 +125,25 @@ def test_order_sort_and_tile_scores_against_torch():
     # more items than one block sorts, no scratch buffer: refused
     rc = _abi.lib.rm_tile_order_from_cost(_abi.ptr(cost_d), 777_777, 255, _abi.ptr(order), None, stream)
     assert rc == -1 and b"scratch" in _abi.lib.rm_last_error()
-    T, S = 3000, 128
+    cams, tx, ty, S = 2, 50, 30, 128
+    T = cams * tx * ty
     ray = torch.randint(0, 60, (T, 64), generator=gen, dtype=torch.int32)
-    for i in range(0, T, 3):                                               # every third tile gets some long rays
+    for i in range(0, T, 7):                                               # every seventh tile gets some long rays
         k = int(torch.randint(1, 65, (1,), generator=gen))
         ray[i, :k] = torch.randint(96, S + 1, (k,), generator=gen, dtype=torch.int32)
-    score = torch.empty(T, dtype=torch.int32, device=DEV)
     ray_d = ray.to(DEV)
-    _abi.check(_abi.lib.rm_tile_score_from_ray_cost(_abi.ptr(ray_d), T, S, _abi.ptr(score), stream), "score")
-    n_long = (ray >= 96).sum(dim=1)
-    want = torch.where(n_long > 0, torch.clamp(16 + (n_long - 1) // 4, max=31), (ray.max(dim=1).values.long() * 16) // (S + 1))
-    assert torch.equal(score.cpu().long(), want)
+    for reach in (0, 1, 2):
+        score = torch.empty(T, dtype=torch.int32, device=DEV)
+        raw = torch.empty(T, dtype=torch.int32, device=DEV)
+        _abi.check(_abi.lib.rm_tile_score_from_ray_cost(_abi.ptr(ray_d), T, tx, ty, reach, S, _abi.ptr(raw), _abi.ptr(score), stream), "score")
+        n_long = (ray >= 96).sum(dim=1).view(cams, 1, ty, tx).float()
+        mx = ray.max(dim=1).values.view(cams, 1, ty, tx).float()
+        k = 2 * reach + 1
+        near_long = torch.nn.functional.max_pool2d(n_long, k, 1, reach).long().flatten()
+        near_max = torch.nn.functional.max_pool2d(mx, k, 1, reach).long().flatten()
+        own = n_long.long().flatten()
+        want = torch.where(own > 0, 17 + ((own - 1) * 15) // 64, torch.where(near_long > 0, torch.full_like(own, 16), (near_max * 16) // (S + 1)))
+        assert torch.equal(score.cpu().long(), want), reach
 
 
 def test_captured_frame_with_regen_follows_the_camera():

@@ -78,7 +78,8 @@ def test_bad_arguments_return_error_codes_without_launching():
         assert regen(**bad) == -1 and b"RM_FLAG_REGEN" in lib.rm_last_error(), bad
     assert lib.rm_tile_order_from_cost(None, 10, 8, None, None, None) == -1
     assert lib.rm_tile_order_from_cost(16, 1 << 20, 8, 16, None, None) == -1 and b"scratch" in lib.rm_last_error()
-    assert lib.rm_tile_score_from_ray_cost(16, 0, 8, 16, None) == -1
+    assert lib.rm_tile_score_from_ray_cost(16, 0, 1, 1, 1, 8, 16, 16, None) == -1
+    assert lib.rm_tile_score_from_ray_cost(16, 10, 3, 3, 1, 8, 16, 16, None) == -1       # 10 tiles are no 3 x 3 grid
     cam64 = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4, dtype=2)
     assert render(0, cam_=cam64) == -1 and b"camera dtype" in lib.rm_last_error()
     assert lib.rm_wave_tiles(1, 1080, 1920, _abi.FLAG_TILE8X8) == 135 * 240
