@@ -148,7 +148,11 @@ enum {
 };
 
 /* Workspace ("minmax") layout, uint32 words, prepared by rm_minmax_init before every launch
- * that uses it: [0] global min, [1] global max (order-preserving encoding), [2] NaN flag,
+ * that uses it: [0] global min, [1] global max (order-preserving encoding), [2] NaN flag -- as written by
+ * rm_minmax_encode -- plus RM_WORK_MM_SLOTS partial {min, max, NaN flag} triples at
+ * [RM_WORK_MM_BASE + s*32], one 128-B line each, which the frame kernels fold their waves' values into (5000 waves
+ * folding into ONE word triple cost 60-100 us of serialised atomics per frame); the global value is the combination
+ * of all of them (rm_minmax_decode, rm_shade_finish).
  * [RM_WORK_QUEUE_BASE + q*RM_WORK_QUEUE_STRIDE] tile counter of queue q. */
 #define RM_WORK_QUEUES 64
 #define RM_WORK_QUEUE_STRIDE 32
@@ -156,7 +160,9 @@ enum {
 #define RM_WORK_PARK_BASE (RM_WORK_QUEUE_BASE + RM_WORK_QUEUES * RM_WORK_QUEUE_STRIDE)
 #define RM_PARK_LISTS 8          /* one list of parked rays per check step (see rm_render_forward: park_ws) */
 #define RM_PARK_SHARDS 4         /* counters per list, each on its own 128-B line */
-#define RM_WORK_WORDS (RM_WORK_PARK_BASE + RM_PARK_LISTS * RM_PARK_SHARDS * 32)
+#define RM_WORK_MM_BASE (RM_WORK_PARK_BASE + RM_PARK_LISTS * RM_PARK_SHARDS * 32)
+#define RM_WORK_MM_SLOTS 64
+#define RM_WORK_WORDS (RM_WORK_MM_BASE + RM_WORK_MM_SLOTS * 32)
 
 int rm_abi_version(void);
 const char* rm_last_error(void);

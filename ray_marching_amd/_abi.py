@@ -35,7 +35,7 @@ _DTYPES = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.float64: DT
 def dtype_code(dtype) -> int:
     """RM_DTYPE_* of a torch dtype (KeyError for anything the kernels cannot read or write)."""
     return _DTYPES[dtype]
-WORK_WORDS = 64 + 64 * 32 + 8 * 4 * 32   # RM_WORK_WORDS (min/max words, tile queues, parking counters)
+WORK_WORDS = 64 + 64 * 32 + 8 * 4 * 32 + 64 * 32   # RM_WORK_WORDS (min/max words, tile queues, parking counters, min/max slots)
 CAMERA_BWD_BLOCKS = 256     # RM_CAMERA_BWD_BLOCKS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 

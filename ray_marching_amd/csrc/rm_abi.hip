@@ -398,13 +398,13 @@ int rm_minmax_init(uint32_t* minmax, void* stream) {
 
 int rm_minmax_decode(const uint32_t* minmax, float* lohi, void* stream) {
   if (!minmax || !lohi) return fail(RM_E_BADARG, "rm_minmax_decode: null");
-  rm::k_minmax_decode<<<1, 1, 0, (hipStream_t)stream>>>(minmax, lohi);
+  rm::k_minmax_decode<<<1, 64, 0, (hipStream_t)stream>>>(minmax, lohi);
   return launched("k_minmax_decode");
 }
 
 int rm_minmax_encode(const float* lohi, uint32_t* minmax, void* stream) {
   if (!minmax || !lohi) return fail(RM_E_BADARG, "rm_minmax_encode: null");
-  rm::k_minmax_encode<<<1, 1, 0, (hipStream_t)stream>>>(lohi, minmax);
+  rm::k_minmax_encode<<<1, 64, 0, (hipStream_t)stream>>>(lohi, minmax);
   return launched("k_minmax_encode");
 }
 

@@ -810,7 +810,9 @@ RM_DEV Shaded shade_pixel(int mode, const ShadeIn& s, int cmap_size, int degree)
   }
 }
 
-// fold a wave's running min/max (+NaN flag) into the global minmax words
+// fold a wave's running min/max (+NaN flag) into one of the workspace's partial triples (include/rm_abi.h): every
+// wave of a frame folding into the SAME three words serialises ~15000 atomics at one L2 line -- 60 us of the 470 us
+// distance-shader frame at 1080p
 RM_DEV void fold_minmax(uint32_t* minmax, float lo, float hi, bool saw_nan) {
   for (int o = 32; o > 0; o >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, o, 64));
@@ -818,10 +820,26 @@ RM_DEV void fold_minmax(uint32_t* minmax, float lo, float hi, bool saw_nan) {
   }
   unsigned long long nanmask = __ballot(saw_nan);
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&minmax[0], f2ord(lo));
-    atomicMax(&minmax[1], f2ord(hi));
-    if (nanmask) atomicOr(&minmax[2], 1u);
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t* slot = minmax + RM_WORK_MM_BASE + 32 * (wave % RM_WORK_MM_SLOTS);
+    atomicMin(&slot[0], f2ord(lo));
+    atomicMax(&slot[1], f2ord(hi));
+    if (nanmask) atomicOr(&slot[2], 1u);
   }
+}
+
+// the global {min, max, NaN flag}: words 0-2 combined with the partial triples; every lane of the wave gets it
+RM_DEV void load_minmax(const uint32_t* __restrict__ mm, float& lo, float& hi) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t* slot = mm + RM_WORK_MM_BASE + 32 * (lane % RM_WORK_MM_SLOTS);
+  uint32_t a = slot[0], b = slot[1], c = slot[2];
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a2 = __shfl_xor(a, o, 64), b2 = __shfl_xor(b, o, 64), c2 = __shfl_xor(c, o, 64);
+    a = a2 < a ? a2 : a; b = b2 > b ? b2 : b; c |= c2;
+  }
+  a = mm[0] < a ? mm[0] : a; b = mm[1] > b ? mm[1] : b; c |= mm[2];
+  lo = ord2f(a); hi = ord2f(b);
+  if (c) { lo = __builtin_nanf(""); hi = lo; }
 }
 
 // Standalone Shader.forward over tensors (any of the inputs a mode does not read may be null).
@@ -1385,8 +1403,8 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const int32_t* __restric
 
 // second pass for the globally normalised shaders
 __global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
-  float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
-  if (minmax[2]) { lo = __builtin_nanf(""); hi = lo; }
+  float lo, hi;
+  load_minmax(minmax, lo, hi);
   const float gamma = (float)(1.0 / 2.33);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float x = src[3 * i];
@@ -1405,15 +1423,28 @@ __global__ void k_minmax_init(uint32_t* mm) {
   for (int i = threadIdx.x; i < RM_WORK_WORDS; i += blockDim.x) mm[i] = 0u;
   __syncthreads();
   if (threadIdx.x == 0) { mm[0] = f2ord(__builtin_inff()); mm[1] = f2ord(-__builtin_inff()); }
+  if (threadIdx.x < RM_WORK_MM_SLOTS) {
+    mm[RM_WORK_MM_BASE + 32 * threadIdx.x] = f2ord(__builtin_inff());
+    mm[RM_WORK_MM_BASE + 32 * threadIdx.x + 1] = f2ord(-__builtin_inff());
+  }
 }
+// one wave
 __global__ void k_minmax_decode(const uint32_t* mm, float* lohi) {
-  float nanv = __builtin_nanf("");
-  lohi[0] = mm[2] ? nanv : ord2f(mm[0]);
-  lohi[1] = mm[2] ? nanv : ord2f(mm[1]);
+  float lo, hi;
+  load_minmax(mm, lo, hi);
+  if (threadIdx.x == 0) { lohi[0] = lo; lohi[1] = hi; }
 }
+// one wave: the given pair becomes the global value (words 0-2; the partial triples go back to neutral)
 __global__ void k_minmax_encode(const float* lohi, uint32_t* mm) {
-  bool isn = (lohi[0] != lohi[0]) || (lohi[1] != lohi[1]);
-  mm[0] = f2ord(lohi[0]); mm[1] = f2ord(lohi[1]); mm[2] = isn ? 1u : 0u; mm[3] = 0u;
+  if (threadIdx.x == 0) {
+    bool isn = (lohi[0] != lohi[0]) || (lohi[1] != lohi[1]);
+    mm[0] = f2ord(lohi[0]); mm[1] = f2ord(lohi[1]); mm[2] = isn ? 1u : 0u; mm[3] = 0u;
+  }
+  if (threadIdx.x < RM_WORK_MM_SLOTS) {
+    mm[RM_WORK_MM_BASE + 32 * threadIdx.x] = f2ord(__builtin_inff());
+    mm[RM_WORK_MM_BASE + 32 * threadIdx.x + 1] = f2ord(-__builtin_inff());
+    mm[RM_WORK_MM_BASE + 32 * threadIdx.x + 2] = 0u;
+  }
 }
 
 // standalone PinholeCamera.forward

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.rm_abi_version() == _abi.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "rm_abi.h")).read()
     assert f"#define RM_ABI_VERSION {_abi.ABI_VERSION}" in header
-    assert f"#define RM_WORK_WORDS" in header and _abi.WORK_WORDS == 64 + 64 * 32 + 8 * 4 * 32
+    assert f"#define RM_WORK_WORDS" in header and _abi.WORK_WORDS == 64 + 64 * 32 + 8 * 4 * 32 + 64 * 32
 
 
 def test_bad_arguments_return_error_codes_without_launching():
