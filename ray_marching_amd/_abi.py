@@ -80,6 +80,7 @@ _SIGNATURES = {
     "rm_tile_order_from_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P]),
     "rm_tile_score_from_ray_cost": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rm_minmax_init": (C.c_int, [_P, _P]),
+    "rm_minmax_init_many": (C.c_int, [_P, C.c_int32, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),
     "rm_shade_finish": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P]),

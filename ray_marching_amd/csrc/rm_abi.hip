@@ -396,6 +396,12 @@ int rm_minmax_init(uint32_t* minmax, void* stream) {
   return launched("k_minmax_init");
 }
 
+int rm_minmax_init_many(uint32_t* minmax, int32_t count, void* stream) {
+  if (!minmax || count <= 0 || count > 65535) return fail(RM_E_BADARG, "rm_minmax_init_many: bad args");
+  rm::k_minmax_init<<<count, 256, 0, (hipStream_t)stream>>>(minmax);
+  return launched("k_minmax_init");
+}
+
 int rm_minmax_decode(const uint32_t* minmax, float* lohi, void* stream) {
   if (!minmax || !lohi) return fail(RM_E_BADARG, "rm_minmax_decode: null");
   rm::k_minmax_decode<<<1, 64, 0, (hipStream_t)stream>>>(minmax, lohi);

@@ -1420,6 +1420,7 @@ __global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n,
 
 // workspace: words 0-2 global min / max / NaN flag, the rest zero (tile queue counters)
 __global__ void k_minmax_init(uint32_t* mm) {
+  mm += (size_t)blockIdx.x * RM_WORK_WORDS;       // one block per workspace (rm_minmax_init_many)
   for (int i = threadIdx.x; i < RM_WORK_WORDS; i += blockDim.x) mm[i] = 0u;
   __syncthreads();
   if (threadIdx.x == 0) { mm[0] = f2ord(__builtin_inff()); mm[1] = f2ord(-__builtin_inff()); }

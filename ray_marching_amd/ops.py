@@ -300,6 +300,36 @@ def camera_forward(ray_positions, ray_directions, orientation, translation):
     return Camera.apply(orientation, translation, ray_positions, ray_directions)
 
 
+class _Workspaces:
+    """Launch workspaces (RM_WORK_WORDS: min/max words, tile-queue counters) prepared a batch at a time by ONE launch
+    per device and stream, instead of one 5-us launch in front of every frame or backward kernel.  A batch is a fresh
+    allocation (callers may keep a workspace: measurement hooks, the min/max all-reduce), handed out in stream order
+    on the stream it was prepared on.  Under HIP-graph capture every frame prepares its own, so a replay is
+    self-contained."""
+    BATCH = 16
+
+    def __init__(self):
+        self._pools = {}
+
+    def take(self, dev, stream):
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)
+            _abi.check(_lib.rm_minmax_init(_abi.ptr(ws), stream), "rm_minmax_init")
+            return ws
+        key = (dev.index, stream.value)
+        pool = self._pools.get(key)
+        if pool is None or pool[1] == self.BATCH:
+            buf = torch.empty(self.BATCH * _abi.WORK_WORDS, dtype=torch.int32, device=dev)
+            _abi.check(_lib.rm_minmax_init_many(_abi.ptr(buf), self.BATCH, stream), "rm_minmax_init_many")
+            pool = self._pools[key] = [buf, 0]
+        i = pool[1]
+        pool[1] += 1
+        return pool[0][i * _abi.WORK_WORDS:(i + 1) * _abi.WORK_WORDS]
+
+
+workspaces = _Workspaces()
+
+
 # --------------------------------------------------------------------------
 # fused frame
 # --------------------------------------------------------------------------
@@ -379,7 +409,6 @@ class Render(torch.autograd.Function):
         p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if (record or regen) else None
         traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
         nexec = torch.empty(R, dtype=torch.int32, device=dev) if record else None
-        minmax = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)   # global min/max words + dynamic tile counter
         # parking workspace (rays that never settle are finished by a dense second kernel): room for 2 R rays
         # over the 32 list segments; inference frames of >= 48 steps with the early-out only
         park_cap = 0
@@ -390,7 +419,7 @@ class Render(torch.autograd.Function):
             stream = _abi.current_stream(dev)
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(rp, rd)
-            _abi.check(_lib.rm_minmax_init(_abi.ptr(minmax), stream), "rm_minmax_init")
+            minmax = workspaces.take(dev, stream)      # global min/max words + tile-queue counters
             sink = event_sink if event_sink is not None else kernel_event_sink
             if sink is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)
@@ -441,9 +470,8 @@ class Render(torch.autograd.Function):
             s, keep = cs.scene_struct(prm, dev)
             cam = camera_struct(rp, rd)
             part = _partials(cs, prm, dev)
-            work = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=dev)
             stream = _abi.current_stream(dev)
-            _abi.check(_lib.rm_minmax_init(_abi.ptr(work), stream), "rm_minmax_init")
+            work = workspaces.take(dev, stream)
             need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             gpos = torch.empty_like(p_final) if need_pose else None
             gdirs = torch.empty_like(p_final) if ctx.needs_input_grad[1] else None
