@@ -148,17 +148,21 @@ def kernel_in_use(loop):
     return "k_march_regen + k_render_finish" if states[-1]["regen"] else "k_render_fwd"
 
 
-def frame_rate(loop, q, t, rows, frames=20, modes=MODES, steps=STEPS_MARCH, warm=4):
-    """Serial, one-stream frame time of `loop` at pose (q, t): ms per frame."""
+def frame_rate(loop, q, t, rows, frames=20, modes=MODES, steps=STEPS_MARCH, warm=4, blocks=3):
+    """Serial, one-stream frame time of `loop` at pose (q, t): ms per frame, median of `blocks` timed blocks (a single
+    block now and then contains a host stall of tens of milliseconds on a shared box)."""
+    times = []
     with torch.no_grad():
         for i in range(warm):
             loop(q, t, modes[i % len(modes)], 1, steps, rows=rows)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(frames):
-            loop(q, t, modes[i % len(modes)], 1, steps, rows=rows)
-        torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / frames * 1e3
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(frames):
+                loop(q, t, modes[i % len(modes)], 1, steps, rows=rows)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / frames * 1e3)
+    return sorted(times)[len(times) // 2]
 
 
 def config3_probe(dev):

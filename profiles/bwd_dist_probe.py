@@ -26,7 +26,7 @@ Hn = int(ops.bwd_last_work[32])
 print(f"rays handed to the deferred-ray kernels: {Hn} of {h * w}")
 hard, cap = ops.bwd_last_hard
 top = hard[cap:2 * cap].view(torch.int32)[:Hn].long()
-gbuf = hard[10 * cap + steps * cap * 4:].view(steps, cap)[:, :Hn]
+gbuf = hard[10 * cap + steps * cap * 4:10 * cap + steps * cap * 5].view(steps, cap)[:, :Hn]
 need = (torch.arange(steps, device=dev)[:, None] <= top[None, :])
 nz = (gbuf != 0) & need
 grp = (Hn + 63) // 64
@@ -67,5 +67,7 @@ hard = (walked >= 32).nonzero().flatten()
 mv = (traj[1:] - traj[:-1]).abs().amax(-1)                  # [S-1, R] per-step movement
 mv_t = mv.t().reshape(h // 8, 8, w // 8, 8, steps - 1).permute(0, 2, 1, 3, 4).reshape(-1, 64, steps - 1)[hard]   # [hard tiles, 64 lanes, S-1]
 last = mv_t[:, :, -8:].amax(-1)                              # largest move in the last 8 steps, per lane
-for thr in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2):
+if hard.numel() == 0:
+    print('no tile walks 32 or more steps in place any more (round 1: 15 % of the tiles walked all 64)')
+for thr in (() if hard.numel() == 0 else (1e-6, 1e-5, 1e-4, 1e-3, 1e-2)):
     print(f"hard tiles ({len(hard)}): lanes still moving > {thr:g} in the last 8 steps: mean {(last > thr).float().sum(1).mean():.1f} of 64; tiles with none: {((last > thr).sum(1) == 0).float().mean():.3f}")
