@@ -936,10 +936,13 @@ struct MinMaxAcc {
 template <class SceneT>
 RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T, const TileRays& r, V3 p, int nexec,
                         MinMaxAcc& mm, bool store_p = true) {
-  float dist = scene.eval(p);
+  const int mode = a.mode;
+  // scene(p) (control.py:244) is only looked at by the proximity shader and, as the centre tap, by the Laplacian:
+  // the other six modes skip the evaluation -- a fifth of this epilogue's scene evaluations
+  float dist = 0.0f;
+  if (mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN) dist = scene.eval(p);
   V3 n = mk3(0.0f, 0.0f, 0.0f);
   float lap = 0.0f;
-  const int mode = a.mode;
   if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap);
   ShadeIn si;
   si.o = r.o; si.v = r.v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
