@@ -77,6 +77,7 @@ class CompiledScene:
     signature: tuple                    # topology key (ops + offsets), parameters excluded
     _device_programs: dict = field(default_factory=dict)
     _table: dict = field(default_factory=dict)
+    _leaf_sizes: object = None
     _lib: object = None
 
     # the loaded libraries (ctypes) and device tensors are process state, not scene state: a pickled / deep-copied
@@ -127,6 +128,12 @@ class CompiledScene:
         if not leaves:
             return torch.zeros(1, dtype=torch.float32, device=device)
         return torch.cat([p.reshape(-1).to(device=device, dtype=torch.float32) for p in leaves])
+
+    @property
+    def leaf_sizes(self):
+        if self._leaf_sizes is None:
+            self._leaf_sizes = [p.numel() for p in self.leaves]
+        return self._leaf_sizes
 
     def param_table(self, device):
         """Device table of RmParamRef {pointer, element, dtype} for every float of the block, so the kernels

@@ -369,10 +369,10 @@ class RenderLoop(nn.Module):
             tile_order, tile_cost, after = self._tile_schedule(rp, rows, steps, regen, record_now)
         params, leaves = None, ()
         if training or _AB_PACK:
-            if _AB_PACK or cs.param_table(rp.device) is None:
+            if _AB_PACK:
                 params = cs.pack_params(rp.device)
-            else:
-                leaves = cs.leaves
+            else:       # parameters that cannot be read in place are packed (without grad) inside scene_struct;
+                leaves = cs.leaves      # their gradients still go to the leaves
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
                                  flags, allreduce_minmax, self.precision, None, tile_order, tile_cost, leaves, events)

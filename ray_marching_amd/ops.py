@@ -40,8 +40,8 @@ def _io(t: torch.Tensor):
     return t.contiguous(), _abi.dtype_code(t.dtype)
 
 
-def _partials(cs: CompiledScene, params, device):
-    s, keep = cs.scene_struct(params, device)
+def _partials(cs: CompiledScene, s, device):
+    """Workspace of the backward kernels' per-block partial sums for the scene struct ``s``."""
     n = cs.lib(True).rm_grad_partials_floats(s, 0)
     return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
 
@@ -108,7 +108,7 @@ class SDFEval(torch.autograd.Function):
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            part = _partials(cs, prm, dev)
+            part = _partials(cs, s, dev)
             _ck(cs, cs.lib(True).rm_sdf_backward(s, _abi.ptr(pts), _abi.ptr(g), _abi.ptr(gpts), _abi.ptr(gprm),
                                             _abi.ptr(part), n, _abi.current_stream(dev)), "rm_sdf_backward")
         gp = gpts.view(*grad_out.shape[:-1], 3).to(ctx.in_dtype) if gpts is not None else None
@@ -161,7 +161,7 @@ class March(torch.autograd.Function):
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            part = _partials(cs, prm, dev)
+            part = _partials(cs, s, dev)
             _ck(cs, cs.lib(True).rm_march_backward(s, _abi.ptr(v), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(g),
                                               _abi.ptr(gpos), _abi.ptr(gdirs), _abi.ptr(gprm), _abi.ptr(part),
                                               n, steps, _abi.current_stream(dev)), "rm_march_backward")
@@ -221,7 +221,7 @@ class Normals(torch.autograd.Function):
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             s, keep = cs.scene_struct(prm, dev)
-            part = _partials(cs, prm, dev)
+            part = _partials(cs, s, dev)
             _ck(cs, cs.lib(True).rm_normals_backward(s, ctx.tetra, _abi.ptr(pts), _abi.ptr(gn), _abi.ptr(gl),
                                                 _abi.ptr(gpts), _abi.ptr(gprm), _abi.ptr(part), n,
                                                 _abi.current_stream(dev)), "rm_normals_backward")
@@ -452,6 +452,7 @@ class Render(torch.autograd.Function):
             # the leaves are saved too: autograd then refuses a backward after an in-place edit of a parameter
             # (the backward kernels read the live storages, which must still hold the forward's values)
             ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
+            ctx.scene_keep = keep       # (program, packed block or None, pointer table or None): what backward reads through
             ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
             ctx.precision, ctx.cmap, ctx.degree = precision, cmap, degree
         return image
@@ -466,10 +467,12 @@ class Render(torch.autograd.Function):
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
+        lib = cs.lib(True, ctx.precision)
         with torch.cuda.device(dev):
-            s, keep = cs.scene_struct(prm, dev)
+            # the forward's own view of the parameters (its packed copy or pointer table): no second look at 40 storages
+            s, keep = cs.scene_struct(prm if prm is not None else ctx.scene_keep[1], dev, table=ctx.scene_keep[2])
             cam = camera_struct(rp, rd)
-            part = _partials(cs, prm, dev)
+            part = _partials(cs, s, dev)
             stream = _abi.current_stream(dev)
             work = workspaces.take(dev, stream)
             need_pose = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -486,14 +489,14 @@ class Render(torch.autograd.Function):
                 if hard_cap else None
             if bwd_tile_cost_sink is not None:             # measurement runs: word 32 of `work` = rays deferred
                 globals()["bwd_last_work"], globals()["bwd_last_hard"] = work, (hard, hard_cap)
-            _abi.check(cs.lib(True, ctx.precision).rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
+            _abi.check(lib.rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
                                                _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
                                                _abi.ptr(gqdir), _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                                0 if cmap is None else _abi.dtype_code(cmap.dtype),
                                                ctx.mode, ctx.degree, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags,
                                                _abi.ptr(bwd_tile_cost_sink), _abi.ptr(hard), hard_cap, stream),
-                       "rm_render_backward", cs.lib(True, ctx.precision))
+                       "rm_render_backward", lib)
         gq = gt = None
         if need_pose:
             gq, gt = _camera_backward(rp, rd, q, gpos, gdirs, ctx.rows, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
@@ -507,12 +510,14 @@ class Render(torch.autograd.Function):
         gp_out = gprm[: prm.numel()] if (prm is not None and ctx.needs_input_grad[0]) else None
         leaf_grads = []
         if leaves:                              # named_parameters() order = block order: one split, then views
-            pieces = torch.split(gprm[: cs.n_params], [p.numel() for p in leaves])
+            pieces = torch.split(gprm[: cs.n_params], cs.leaf_sizes)
+            need = ctx.needs_input_grad
             for k, (p, g) in enumerate(zip(leaves, pieces)):
-                if not ctx.needs_input_grad[_N_FIXED_ARGS + k]:
+                if not need[_N_FIXED_ARGS + k]:
                     leaf_grads.append(None)
                     continue
-                g = g.view(p.shape)
+                if p.dim() != 1:
+                    g = g.view(p.shape)
                 leaf_grads.append(g if p.dtype == torch.float32 else g.to(p.dtype))
         return (gp_out, gq, gt) + (None,) * (_N_FIXED_ARGS - 3) + tuple(leaf_grads)
 
