@@ -226,7 +226,10 @@ class RenderLoop(nn.Module):
         the scene, 0.6 % of the headline."""
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
-        key = (r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream)
+        return self._choose_kernel_for((r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream))
+
+    def _choose_kernel_for(self, key):
+        """The state machine of _choose_kernel for one (band, step count, stream)."""
         st = self._choice_state.get(key)
         if st is None:
             st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}, "skip": 0}

@@ -413,3 +413,53 @@ def test_product_never_imports_the_oracle():
             assert not uses or fn.name == allowed, f"{fname}:{fn.name} imports the oracle"
         top_level = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
         assert not any((getattr(n, "module", "") or "").startswith("oracle") for n in top_level)
+
+
+def test_auto_kernel_choice_state_machine():
+    """RenderLoop(regen="auto"): probe in the first frame of a cycle, the kernel in use timed in the second, switch
+    when the other one was > 3 % faster (confirmed in the next cycle), else look again every fourth cycle.  Driven
+    here with stand-in timing events."""
+    from ray_marching_amd.control import RenderLoop
+
+    class Ev:
+        def __init__(self, ms, ready=True):
+            self.ms, self.ready = ms, ready
+
+        def query(self):
+            return self.ready
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    loop = RenderLoop.__new__(RenderLoop)                     # the state machine needs no module state
+    loop._choice_state, loop.adaptive_order = {}, 4
+    speed = {"tile": 400.0, "regen": 300.0}
+
+    def frame():
+        regen, record, sink = loop._choose_kernel_for("k")
+        if sink is not None:
+            sink.append((Ev(0.0), Ev(speed["regen" if regen else "tile"])))
+        return regen, record, sink is not None
+
+    log = [frame() for _ in range(4 * 12)]
+    assert log[0] == (True, True, True) and log[1] == (False, False, True)      # probe of the pools, then the tile kernel timed
+    assert log[2][0] is True and log[3] == (True, False, False)                 # the pools were faster: in use from frame 2 on
+    assert log[4] == (False, True, True) and log[5] == (True, False, True)      # next cycle: the tile kernel is looked at
+    # it stays slower: probes only every fourth cycle from now on
+    probes = [i for i, (regen, record, timed) in enumerate(log) if record]
+    assert probes == [0, 4, 20, 36], probes
+    assert all(regen for i, (regen, _, _) in enumerate(log) if i >= 2 and i not in probes)
+    # the scene changes: the tile kernel becomes the faster one; the next probe finds out
+    speed.update(tile=200.0)
+    log2 = [frame() for _ in range(4 * 8)]
+    assert log2[-1][0] is False
+    # a measurement that is not ready yet decides nothing (and blocks nothing)
+    loop._choice_state.clear()
+    r, rec, sink = loop._choose_kernel_for("k")
+    pending = Ev(1.0, ready=False)
+    sink.append((Ev(0.0), pending))
+    r1, _, sink1 = loop._choose_kernel_for("k")
+    sink1.append((Ev(0.0), Ev(500.0)))
+    assert loop._choose_kernel_for("k")[0] is False and loop._choice_state["k"]["regen"] is False
+    pending.ready, pending.ms = True, 100.0
+    assert loop._choose_kernel_for("k")[0] is True
