@@ -318,6 +318,8 @@ class _Workspaces:
             return ws
         key = (dev.index, stream.value)
         pool = self._pools.get(key)
+        if pool is None and len(self._pools) >= 64:      # streams come and go: forget the batches of old ones
+            self._pools.clear()
         if pool is None or pool[1] == self.BATCH:
             buf = torch.empty(self.BATCH * _abi.WORK_WORDS, dtype=torch.int32, device=dev)
             _abi.check(_lib.rm_minmax_init_many(_abi.ptr(buf), self.BATCH, stream), "rm_minmax_init_many")
