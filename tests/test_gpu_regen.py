@@ -178,3 +178,21 @@ def test_auto_mode_takes_the_faster_kernel():
                     torch.cuda.synchronize()
         (st,) = auto._choice_state.values()
         assert st["regen"] is want_regen, (z, st)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_regen_random_scene_trees_equal_tile_kernel(seed):
+    """Random compositions of all 11 node types through the interpreter: pool kernels == tile kernel, bit for bit
+    (NaN pixels included), at a pose inside and a pose outside the geometry, for a shader of each kind."""
+    gen = torch.Generator().manual_seed(4000 + seed)
+    spec = H.random_spec(gen)
+    n, h, w, steps = 1, 268, 284, 40
+    tile = H.make_loop(H.spec_to_module(spec), h, w, n=n, regen=False, adaptive_order=0)
+    pool = H.make_loop(H.spec_to_module(spec), h, w, n=n, regen=True, adaptive_order=2)
+    for z in (-4.0, 0.3):
+        q, t = _poses(n, z, 50 + seed)
+        for mode in (0, 2, 5, 7):
+            with torch.no_grad():
+                want = tile(q, t, mode, 3, steps)
+                for frame in range(2):
+                    assert _same_bits(pool(q, t, mode, 3, steps), want), (seed, z, mode, frame)
