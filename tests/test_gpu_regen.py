@@ -196,3 +196,37 @@ def test_regen_random_scene_trees_equal_tile_kernel(seed):
                 want = tile(q, t, mode, 3, steps)
                 for frame in range(2):
                     assert _same_bits(pool(q, t, mode, 3, steps), want), (seed, z, mode, frame)
+
+
+@pytest.mark.parametrize("z", [-3.0, 1.0])
+def test_regen_config3_full_size_fp16(z):
+    """BASELINE configs[2] (3840x2160, 256 steps, float16 module): pool kernels with natural, tile-score and per-ray
+    dealing orders == tile kernel, bit for bit."""
+    h, w, steps = 2160, 3840, 256
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV).half()
+    t = torch.tensor([[0.0, 0.0, z]], device=DEV).half()
+    tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0).to(torch.float16)
+    with torch.no_grad():
+        want = {m: tile(q, t, m, 1, steps) for m in (4, 0)}
+    del tile
+    for per_ray in (False, True):
+        pool = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=True, order_per_ray=per_ray, adaptive_order=2).to(torch.float16)
+        with torch.no_grad():
+            for frame in range(3):
+                for m in (4, 0):
+                    assert _same_bits(pool(q, t, m, 1, steps), want[m]), (z, per_ray, frame, m)
+        del pool
+
+
+def test_regen_config5_band_full_size():
+    """BASELINE configs[4]: rows 1620..2160 of the 7680x4320 frame of the 32-primitive scene, 256 steps."""
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
+    h, w, steps = 4320, 7680, 256
+    band = (1620, 2160)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -4.5]], device=DEV)
+    tile = H.make_loop(make_many_primitive_scene(32), h, w, regen=False, rows=band)
+    pool = H.make_loop(make_many_primitive_scene(32), h, w, regen=True, rows=band, adaptive_order=2)
+    with torch.no_grad():
+        want = tile(q, t, 4, 1, steps, rows=band)
+        for frame in range(3):
+            assert _same_bits(pool(q, t, 4, 1, steps, rows=band), want), frame
