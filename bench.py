@@ -132,7 +132,7 @@ def pipelined_probe(loop, q, t, rows, dev, rays_per_frame, frames=40, nstreams=2
                     loop(q, t, MODES[i % len(MODES)], 1, STEPS_MARCH, rows=rows)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
-    run(6)
+    run(40)         # per stream: workspace batches, the regen="auto" probe of the first cycle and its decision
     dt = run(frames)
     return {"streams": nstreams, "frames": frames, "ms_per_frame": dt / frames * 1e3,
             "value": rays_per_frame * frames / dt / 1e6, "unit": "Mrays/s"}
