@@ -220,10 +220,12 @@ class RenderLoop(nn.Module):
         frame's timing events or None).  Frames come in cycles of `adaptive_order` (16 if that is off): the first one
         of a cycle runs the kernel NOT in use (and renews its dealing order, so that it is measured with an order as old
         as it would be in use), the second one the kernel in use, both between timing events on the launch stream that
-        are looked at -- without waiting -- by later frames; the other kernel takes over when it was more than 3 %
-        faster (and is confirmed in the next cycle), otherwise it is looked at again every fourth cycle.  A probe costs
-        one frame in 64 the difference between the two kernels plus the order renewal: ~85 us at 1080p in front of
-        the scene, 0.6 % of the headline."""
+        are looked at -- without waiting -- by later frames.  The pools take over when they were more than 3 % faster
+        and are then checked against the tile kernel every cycle (it takes over again as soon as it is faster at all);
+        while the tile kernel is in use the pools are looked at every fourth cycle: such a probe costs their time plus
+        the order renewal, ~85 us at 1080p in front of the scene, 0.6 % of the headline.  The choice follows the GPU
+        only as closely as the host does: a loop that enqueues hundreds of frames without ever waiting decides for
+        frames the GPU renders much later."""
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
         return self._choose_kernel_for((r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream))
@@ -232,30 +234,44 @@ class RenderLoop(nn.Module):
         """The state machine of _choose_kernel for one (band, step count, stream)."""
         st = self._choice_state.get(key)
         if st is None:
-            st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}, "skip": 0}
+            st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}, "skip": 0, "log": []}
         for name in list(st["pending"]):
             pair = st["pending"][name]
             if pair and pair[0][1].query():
                 st["ms"][name] = pair[0][0].elapsed_time(pair[0][1])
                 del st["pending"][name]
         if len(st["ms"]) == 2:
-            if st["ms"]["other"] < 0.97 * st["ms"]["used"]:
-                st["regen"] = not st["regen"]
-                st["skip"] = 0          # look again in the next cycle: confirms the switch with a fresh order
+            st["log"].append((st["n"], st["regen"], round(st["ms"]["other"], 4), round(st["ms"]["used"], 4)))   # diagnostics
+            del st["log"][:-64]
+            # Asymmetric on purpose (profiles/orbit_probe.py, a camera flying through the scene): the pools in the wrong
+            # place cost +25 %, the tile kernel in the wrong place misses 12-16 %; a probe of the tile kernel is free
+            # where it is the faster one, a probe of the pools costs their time plus an order renewal.
+            if st["regen"]:
+                if st["ms"]["other"] < st["ms"]["used"]:
+                    st["regen"] = False
+                # while the pools are in use (or were a moment ago) the tile kernel is looked at every cycle, every
+                # second one where it is far behind
+                st["skip"] = 1 if st["ms"]["other"] > 1.15 * st["ms"]["used"] else 0
+            elif st["ms"]["other"] < 0.97 * st["ms"]["used"]:
+                st["regen"] = True
+                st["skip"] = 0
             else:
-                st["skip"] = 3          # the kernel in use stays: the other one is looked at every fourth cycle
+                st["skip"] = 3          # the tile kernel stays: the pools are looked at every fourth cycle
             st["ms"] = {}
         cycle = self.adaptive_order if self.adaptive_order > 0 else 16
         phase = st["n"] % cycle
         st["n"] += 1
         if cycle > 1 and phase == 0:
-            st["ms"], st["pending"] = {}, {}
             if st["skip"] > 0:
                 st["skip"] -= 1
-            else:
+            elif not st["pending"] and not st["ms"]:
+                # (a host that runs many frames ahead of the GPU finds the previous pair of measurements still
+                # unfinished here: it waits for them instead of starting over)
                 st["pending"]["other"] = []
+                st["await_used"] = True
                 return (not st["regen"]), True, st["pending"]["other"]
-        if cycle > 1 and phase == 1 and ("other" in st["pending"] or "other" in st["ms"]):
+        if cycle > 1 and phase == 1 and st.get("await_used"):
+            st["await_used"] = False
             st["pending"]["used"] = []
             return st["regen"], False, st["pending"]["used"]
         return st["regen"], False, None

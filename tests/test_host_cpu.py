@@ -416,9 +416,10 @@ def test_product_never_imports_the_oracle():
 
 
 def test_auto_kernel_choice_state_machine():
-    """RenderLoop(regen="auto"): probe in the first frame of a cycle, the kernel in use timed in the second, switch
-    when the other one was > 3 % faster (confirmed in the next cycle), else look again every fourth cycle.  Driven
-    here with stand-in timing events."""
+    """RenderLoop(regen="auto"): probe in the first frame of a cycle, the kernel in use timed in the second; the pools
+    take over when > 3 % faster and are then checked against the tile kernel every cycle, which takes over again as
+    soon as it is faster; with the tile kernel in use the pools are looked at every fourth cycle.  Driven here with
+    stand-in timing events."""
     from ray_marching_amd.control import RenderLoop
 
     class Ev:
@@ -445,14 +446,17 @@ def test_auto_kernel_choice_state_machine():
     assert log[0] == (True, True, True) and log[1] == (False, False, True)      # probe of the pools, then the tile kernel timed
     assert log[2][0] is True and log[3] == (True, False, False)                 # the pools were faster: in use from frame 2 on
     assert log[4] == (False, True, True) and log[5] == (True, False, True)      # next cycle: the tile kernel is looked at
-    # it stays slower: probes only every fourth cycle from now on
+    # while the pools are in use the tile kernel is looked at again and again: every second cycle where it is > 15 % behind
     probes = [i for i, (regen, record, timed) in enumerate(log) if record]
-    assert probes == [0, 4, 20, 36], probes
+    assert probes == [0, 4] + list(range(12, 48, 8)), probes
     assert all(regen for i, (regen, _, _) in enumerate(log) if i >= 2 and i not in probes)
-    # the scene changes: the tile kernel becomes the faster one; the next probe finds out
+    # the scene changes: the tile kernel becomes the faster one; the next probe finds out and it takes over at once ...
     speed.update(tile=200.0)
-    log2 = [frame() for _ in range(4 * 8)]
-    assert log2[-1][0] is False
+    log2 = [frame() for _ in range(4 * 20)]
+    probes2 = [i for i, (regen, record, timed) in enumerate(log2) if record]
+    assert probes2[0] <= 4 and log2[probes2[0] + 2][0] is False and log2[-1][0] is False
+    # ... and from then on the pools are only looked at every fourth cycle
+    assert probes2[1] - probes2[0] == 4 and all(b - a == 16 for a, b in zip(probes2[1:], probes2[2:])), probes2
     # a measurement that is not ready yet decides nothing (and blocks nothing)
     loop._choice_state.clear()
     r, rec, sink = loop._choose_kernel_for("k")
@@ -463,3 +467,33 @@ def test_auto_kernel_choice_state_machine():
     assert loop._choose_kernel_for("k")[0] is False and loop._choice_state["k"]["regen"] is False
     pending.ready, pending.ms = True, 100.0
     assert loop._choose_kernel_for("k")[0] is True
+
+
+def test_auto_kernel_choice_survives_a_host_far_ahead_of_the_gpu():
+    """Timing events that complete dozens of frames after they were recorded (the host enqueues faster than the GPU
+    renders) must still lead to a decision: measurements in flight are waited for, not started over."""
+    from ray_marching_amd.control import RenderLoop
+
+    class Ev:
+        def __init__(self, ms):
+            self.ms, self.ready = ms, False
+
+        def query(self):
+            return self.ready
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    loop = RenderLoop.__new__(RenderLoop)
+    loop._choice_state, loop.adaptive_order = {}, 4
+    in_flight = []
+    for frame in range(200):
+        regen, record, sink = loop._choose_kernel_for("k")
+        if sink is not None:
+            ev = Ev(300.0 if regen else 400.0)
+            sink.append((Ev(0.0), ev))
+            in_flight.append((frame, ev))
+        for f0, ev in in_flight:                  # the GPU is 40 frames behind
+            if frame - f0 >= 40:
+                ev.ready = True
+    assert loop._choice_state["k"]["regen"] is True and len(loop._choice_state["k"]["log"]) >= 2
