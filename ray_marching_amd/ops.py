@@ -438,7 +438,8 @@ class Render(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
                 sink.append((ev0, ev1))
-                globals()["fwd_last_work"] = minmax       # measurement runs: the workspace words of this frame
+                if event_sink is None:
+                    globals()["fwd_last_work"] = minmax   # measurement runs (kernel_event_sink): the workspace words of this frame
             if mode in _GLOBAL_MODES:
                 if allreduce_minmax is not None:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
