@@ -230,3 +230,27 @@ def test_regen_config5_band_full_size():
         want = tile(q, t, 4, 1, steps, rows=band)
         for frame in range(3):
             assert _same_bits(pool(q, t, 4, 1, steps, rows=band), want), frame
+
+
+def test_regen_with_the_minmax_hook_of_a_row_tiled_render():
+    """Globally normalised shaders over two row bands, min/max folded across the launches through the
+    allreduce_minmax hook (what RowTileRenderer does across ranks): pools == tile kernel == the unsplit frame."""
+    n, h, w, steps = 1, 272, 296, 32
+    q, t = _poses(n, 1.0, 9)
+    tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0)
+    pool = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=True)
+    for mode in (1, 2, 5):
+        with torch.no_grad():
+            whole = tile(q, t, mode, 1, steps)
+            for loop in (tile, pool):
+                # pass 1: every band reports its min/max; pass 2: every band normalises with the global pair
+                seen = []
+                for band in ((0, 100), (100, h)):
+                    loop(q, t, mode, 1, steps, rows=band, allreduce_minmax=lambda lohi: seen.append(lohi.clone()))
+                lo = torch.stack([s[0] for s in seen]).min()
+                hi = torch.stack([s[1] for s in seen]).max()
+
+                def globalise(lohi):
+                    lohi[0], lohi[1] = lo, hi
+                parts = [loop(q, t, mode, 1, steps, rows=band, allreduce_minmax=globalise) for band in ((0, 100), (100, h))]
+                assert _same_bits(torch.cat(parts, dim=1), whole), (mode, loop is pool)
