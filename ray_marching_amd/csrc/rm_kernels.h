@@ -202,6 +202,20 @@ RM_DEV bool same_bits(V3 a, V3 b) {
 #define RM_EARLY_DENSE_STEPS 8    // look for cycles after every 2nd step up to here, after every 4th from then on
 #endif                            // (>= 4: the snapshot refreshes at steps 2 and 4 happen inside those looks)
 
+// p + f v, each component one multiplication and one addition (the reference's `distances * directions + positions`,
+// no contraction).  -DRM_PK_UPDATE: x and y through the packed fp32 forms (v_pk_mul_f32 / v_pk_add_f32: the same IEEE
+// results, 4 instructions instead of 6); measured 1080p scene 2 207 -> 204 us, pools unchanged: inside the noise, off
+typedef float rm_v2f __attribute__((ext_vector_type(2)));
+RM_DEV V3 step_point(V3 p, V3 v, float f) {
+#ifdef RM_PK_UPDATE
+  const rm_v2f vxy = {v.x, v.y}, pxy = {p.x, p.y}, ff = {f, f};
+  const rm_v2f r = ff * vxy + pxy;
+  return mk3(r.x, r.y, f * v.z + p.z);
+#else
+  return mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
+#endif
+}
+
 struct NoPark {
   static constexpr bool kEnabled = false;
   RM_DEV bool operator()(int, V3, bool) const { return false; }
@@ -247,7 +261,7 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
     if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
     float f = scene.eval_near(p, (i & 15) ? move : __builtin_nanf(""));
     move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
-    V3 pn = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
+    V3 pn = step_point(p, v, f);
     const int cadence = (i < RM_EARLY_DENSE_STEPS) ? 1 : 3;
     if (early && (i & cadence) == cadence) {
       // Looked at after every second step at first and after every fourth from step RM_EARLY_DENSE_STEPS on
@@ -1221,7 +1235,7 @@ __global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
         const float f = scene.eval_near(p, ((it + j) & 15) ? move : __builtin_nanf(""));
         move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
         prev = p;
-        p = mk3(f * v.x + p.x, f * v.y + p.y, f * v.z + p.z);
+        p = step_point(p, v, f);
       }
       k += 4;
       if (lambda == 0) {
