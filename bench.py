@@ -268,6 +268,9 @@ def backward_probe(dev):
                                text=True, timeout=180)
             if r.returncode == 0:
                 out["graph_fwd_bwd_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["graph_fwd_bwd_ms"]
+                # the replay is the GPU work of a step; an eager loop well above it is waiting for the host (Python,
+                # autograd's 40 AccumulateGrad nodes, ~20 launches), not for the kernels
+                out["eager_loop_is_host_bound"] = bool(wall > 1.1 * out["graph_fwd_bwd_ms"])
             else:
                 log(f"graph leg exited with {r.returncode}")
         except Exception as e:       # noqa: BLE001  (timeout, bad output: report null)
