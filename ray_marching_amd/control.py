@@ -375,8 +375,10 @@ class RenderLoop(nn.Module):
         regen, record_now, events = False, False, None
         if self.regen and tile_order is None and tile_cost is None and ops.regen_applies(
                 ops.default_flags(self.early_out, self.tile8x8, self.dynamic_tiles, True), steps, training):
-            if self.regen == "auto" and self.precision != "exact":
-                pass        # the "fast" build contracts FMAs per kernel: switching kernels between frames could flicker in the last bit
+            if self.regen == "auto" and (self.precision != "exact" or torch.cuda.is_current_stream_capturing()):
+                # the "fast" build contracts FMAs per kernel: switching kernels between frames could flicker in the last
+                # bit; and a frame being captured into a HIP graph cannot carry timing events or a choice made later
+                pass
             elif self.regen == "auto":
                 band = rows if rows is not None else (0, rp.shape[1])
                 if rp.shape[0] * (band[1] - band[0]) * rp.shape[2] >= self.REGEN_AUTO_MIN_RAYS:

@@ -254,3 +254,24 @@ def test_regen_with_the_minmax_hook_of_a_row_tiled_render():
                     lohi[0], lohi[1] = lo, hi
                 parts = [loop(q, t, mode, 1, steps, rows=band, allreduce_minmax=globalise) for band in ((0, 100), (100, h))]
                 assert _same_bits(torch.cat(parts, dim=1), whole), (mode, loop is pool)
+
+
+def test_auto_mode_inside_a_user_graph_capture():
+    """A default RenderLoop (regen="auto") at a size where auto is active, captured by the user with torch.cuda.graph:
+    no timing events, no kernel choice inside the capture; replays render the frame."""
+    h, w, steps = 1080, 1920, 32
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)
+    q, t = _poses(1, -3.0, 2)
+    with torch.no_grad():
+        want = loop(q, t, 4, 1, steps).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            loop(q, t, 4, 1, steps)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            img = loop(q, t, 4, 1, steps)
+        g.replay()
+        torch.cuda.synchronize()
+    assert _same_bits(img, want)
