@@ -237,7 +237,10 @@ class RenderLoop(nn.Module):
             st = self._choice_state[key] = {"regen": False, "n": 0, "pending": {}, "ms": {}, "skip": 0, "log": []}
         for name in list(st["pending"]):
             pair = st["pending"][name]
-            if pair and pair[0][1].query():
+            if not pair:                          # the frame that was to be timed never recorded its events (it raised)
+                st["pending"], st["ms"], st["await_used"] = {}, {}, False
+                break
+            if pair[0][1].query():
                 st["ms"][name] = pair[0][0].elapsed_time(pair[0][1])
                 del st["pending"][name]
         if len(st["ms"]) == 2:
