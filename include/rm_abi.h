@@ -297,8 +297,11 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
 
 /* VJP of rm_render_forward w.r.t. scene parameters and, through the per-ray outputs, the camera pose.  Shader modes
  * with a fused VJP: 0 lambertian, 3 vignette, 4 normal, 6 tangent, 7 spin (the colormap index is piecewise constant;
- * the brightness is differentiated); others return RM_E_BADARG.  For modes 1 and 2 the reference's own gradient is
- * NaN (x^(1/2.33) at the global minimum).
+ * the brightness is differentiated), and 5 laplacian -- for which grad_image[..., 0] must hold dL/d(surface_laplacian)
+ * of the ray: the shader's global normalisation (a division by the frame's largest |Laplacian|, shader.py:81-89) is a
+ * reduction over every pixel, and over every rank of a row-tiled render, and is differentiated by the caller
+ * (ray_marching_amd/ops.py: laplacian_normalisation_vjp).  Others return RM_E_BADARG: for modes 1 and 2 the
+ * reference's own gradient is NaN (x^(1/2.33) at the global minimum).
  * fp32 only (cam->dtype must be RM_DTYPE_F32).  grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
  * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT

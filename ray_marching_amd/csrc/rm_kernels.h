@@ -1600,7 +1600,11 @@ struct DeferToList {
 };
 
 // VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
-template <class Cfg>
+// kLap: the Laplacian shader (mode 5).  Its global normalisation (shader.py:81-89: a division by the frame's largest
+// |Laplacian|, i.e. a reduction over every pixel -- and every rank of a row-tiled render) is differentiated by the
+// host; grad_image[..., 0] is then dL/d(surface_laplacian) of the ray, which goes into the five-tap Laplacian here.
+// A separate instantiation: the centre tap's VJP is a second inlined scene VJP the other modes should not carry.
+template <class Cfg, bool kLap = false>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
@@ -1627,7 +1631,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     V3 gn = mk3(0.0f, 0.0f, 0.0f);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
     float gq0 = 0.0f, gq1 = 0.0f, gq2 = 0.0f, gq3 = 0.0f;     // direct dependence of the shader on the pose quaternion
-    if (a.mode == RM_MODE_LAMBERTIAN) {
+    if constexpr (kLap) {
+      // nothing here: the upstream of this mode is on the Laplacian, not on the normal (normals_backward below)
+    } else if (a.mode == RM_MODE_LAMBERTIAN) {
       float c = -dot_seq(v, n);
       float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
       gn = mk3(-g * v.x, -g * v.y, -g * v.z);
@@ -1709,7 +1715,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     int walked = 0;
     bool deferred = false;
     if (a.mode != RM_MODE_VIGNETTE) {            // the vignette does not depend on the surface at all
-      lam = normals_backward(scene, T, p, gn, 0.0f, false);
+      lam = normals_backward(scene, T, p, gn, kLap ? gi3.x : 0.0f, kLap);
       int ne = a.nexec ? a.nexec[li] : a.steps;
       lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
                           a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);

@@ -336,7 +336,27 @@ workspaces = _Workspaces()
 # fused frame
 # --------------------------------------------------------------------------
 _GLOBAL_MODES = (1, 2, 5)
-_FUSED_VJP_MODES = {0, 3, 4, 6, 7}   # shader modes rm_render_backward differentiates through (1, 2: the reference's gradient is NaN)
+_FUSED_VJP_MODES = {0, 3, 4, 5, 6, 7}   # shader modes rm_render_backward differentiates through (1, 2: the reference's gradient is NaN)
+
+
+def laplacian_normalisation_vjp(grad_image: torch.Tensor, lap: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    """VJP of LaplacianShader's normalisation (shader.py:81-89: lap / lap.abs().max() * -1 + 1, / 2, clamp(0, 1),
+    pow(1 / 2.33), expanded to three channels) in the order autograd walks it; returns dL/d(surface_laplacian)
+    per ray.  ``lap``: the un-normalised Laplacian [...], ``hi``: its largest magnitude over the frame (0-dim).
+    Where the pixel of the largest |Laplacian| has a POSITIVE one the clamped value is 0 and x^(1/2.33) has an
+    infinite slope there: that ray's upstream is inf - inf = NaN, in the reference as here, and every parameter
+    component the ray reaches gets a NaN gradient."""
+    gamma = 1.0 / 2.33
+    gy = grad_image.sum(-1)
+    u = ((lap / hi) * -1.0 + 1.0) / 2.0
+    x = u.clamp(0.0, 1.0)
+    gu = gy * (gamma * x.pow(gamma - 1.0)) * ((u >= 0.0) & (u <= 1.0))
+    ga = gu * 0.5 * -1.0
+    glap = ga / hi
+    ghi = (ga * (-lap / (hi * hi))).sum()
+    top = lap.abs() == hi               # max(): the gradient goes to the largest element(s), evenly (masked_fill on the CPU)
+    return glap + torch.where(top, (ghi / top.sum()) * lap.sign(), torch.zeros_like(glap))
+
 _N_FIXED_ARGS = 18                   # Render.forward arguments in front of *leaves
 
 
@@ -403,7 +423,9 @@ class Render(torch.autograd.Function):
         image = torch.empty((n, nrows, w, 3), dtype=image_dtype, device=dev)
         first_pass = None
         if mode in _GLOBAL_MODES:
-            first_pass = image if image_dtype == torch.float32 else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
+            # (a training frame of the Laplacian shader keeps the un-normalised values for its backward)
+            first_pass = image if (image_dtype == torch.float32 and not (record and mode == 5)) \
+                else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
         regen = regen_applies(flags, steps, record)
         if not regen:
             flags &= ~(_abi.FLAG_REGEN | _abi.FLAG_ORDER_PER_RAY)
@@ -440,10 +462,12 @@ class Render(torch.autograd.Function):
                 sink.append((ev0, ev1))
                 if event_sink is None:
                     globals()["fwd_last_work"] = minmax   # measurement runs (kernel_event_sink): the workspace words of this frame
+            lohi = None
             if mode in _GLOBAL_MODES:
-                if allreduce_minmax is not None:
+                if allreduce_minmax is not None or (record and mode == 5):
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
                     _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
+                if allreduce_minmax is not None:
                     allreduce_minmax(lohi)
                     _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
                 _abi.check(_lib.rm_shade_finish(_abi.ptr(first_pass), _abi.ptr(image), _abi.dtype_code(image_dtype),
@@ -455,6 +479,8 @@ class Render(torch.autograd.Function):
             # the leaves are saved too: autograd then refuses a backward after an in-place edit of a parameter
             # (the backward kernels read the live storages, which must still hold the forward's values)
             ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
+            # Laplacian shader: the un-normalised values and their largest magnitude, for the normalisation's VJP
+            ctx.lap = (first_pass, lohi, allreduce_minmax is not None) if mode == 5 else None
             ctx.scene_keep = keep       # (program, packed block or None, pointer table or None): what backward reads through
             ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
             ctx.precision, ctx.cmap, ctx.degree = precision, cmap, degree
@@ -469,6 +495,12 @@ class Render(torch.autograd.Function):
         prm, q, t, rp, rd, p_final, traj, nexec, *leaves = ctx.saved_tensors
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
+        if ctx.mode == 5:
+            lap3, lohi, across_ranks = ctx.lap
+            if across_ranks:
+                raise NotImplementedError("gradient of the Laplacian shader through a maximum taken across ranks")
+            glap = laplacian_normalisation_vjp(g, lap3[..., 0], lohi[1])
+            g = torch.stack([glap, torch.zeros_like(glap), torch.zeros_like(glap)], dim=-1).contiguous()
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         lib = cs.lib(True, ctx.precision)
         with torch.cuda.device(dev):
