@@ -295,13 +295,13 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
                       float* grad_dirs, float* grad_normals, int32_t mode, int64_t n_pixels,
                       int64_t pixels_per_camera, void* stream);
 
-/* VJP of rm_render_forward w.r.t. scene parameters and, through the per-ray outputs, the camera pose.  Shader modes
- * with a fused VJP: 0 lambertian, 3 vignette, 4 normal, 6 tangent, 7 spin (the colormap index is piecewise constant;
- * the brightness is differentiated), and 5 laplacian -- for which grad_image[..., 0] must hold dL/d(surface_laplacian)
- * of the ray: the shader's global normalisation (a division by the frame's largest |Laplacian|, shader.py:81-89) is a
- * reduction over every pixel, and over every rank of a row-tiled render, and is differentiated by the caller
- * (ray_marching_amd/ops.py: laplacian_normalisation_vjp).  Others return RM_E_BADARG: for modes 1 and 2 the
- * reference's own gradient is NaN (x^(1/2.33) at the global minimum).
+/* VJP of rm_render_forward w.r.t. scene parameters and, through the per-ray outputs, the camera pose, for all eight
+ * shader modes.  0 lambertian, 3 vignette, 4 normal, 6 tangent, 7 spin: grad_image is dL/d(image) (6, 7: the colormap
+ * index is piecewise constant; the brightness is differentiated).  1 distance, 2 proximity, 5 laplacian: the shader's
+ * normalisation by the frame's minimum / maximum (shader.py:33-38, 51-55, 81-89) is a reduction over every pixel -- and
+ * over every rank of a row-tiled render -- and is differentiated by the caller (ray_marching_amd/ops.py:
+ * minmax_normalisation_vjp, laplacian_normalisation_vjp); grad_image[..., 0] must then hold dL/d(un-normalised value)
+ * of the ray: of log(clamp(|origin - p|)), log(clamp(scene(p))) and the surface Laplacian.
  * fp32 only (cam->dtype must be RM_DTYPE_F32).  grad_image: device [N,rows,W,3].  grad_params[n_params] is overwritten.
  * work: nullable uint32[RM_WORK_WORDS] prepared by rm_minmax_init (dynamic tile queues);
  * flags: the RM_FLAG_TILE8X8 choice of the forward call; RM_FLAG_DYNAMIC_TILES; RM_FLAG_EARLY_OUT

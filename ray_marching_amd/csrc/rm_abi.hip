@@ -497,9 +497,8 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   if (int e = check_render(scene, cam, tetra, orientation, translation, steps, row_begin, row_end)) return e;
   if (cam->dtype != RM_DTYPE_F32) return fail(RM_E_BADARG, "rm_render_backward: fp32 camera buffers only");
   const bool mapped = (mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
-  const bool lap = (mode == RM_MODE_LAPLACIAN);
-  if (!(mode == RM_MODE_LAMBERTIAN || mode == RM_MODE_NORMAL || mode == RM_MODE_VIGNETTE || mapped || lap))
-    return fail(RM_E_BADARG, "rm_render_backward: mode %d has no fused VJP (modes 0, 3, 4, 5, 6, 7 have)", mode);
+  if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_render_backward: mode %d not in 0..7", mode);
+  const int kind = (mode == RM_MODE_LAPLACIAN) ? 1 : (mode == RM_MODE_PROXIMITY ? 2 : 0);
   if (mapped && (!cmap || cmap_size <= 0 || cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64))
     return fail(RM_E_BADARG, "rm_render_backward: mode %d needs the colormap of the forward call", mode);
   if (!p_final || !grad_image || !partials || (steps > 0 && !traj)) return fail(RM_E_BADARG, "rm_render_backward: null buffer");
@@ -513,8 +512,9 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype; a.degree = degree;
   a.mode = mode; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags & (RM_FLAG_TILE8X8 | RM_FLAG_DYNAMIC_TILES | RM_FLAG_EARLY_OUT);
   Launch L;
-  if (int e = lap ? pick_launch(rm::k_render_bwd<GB, true>, *scene, true, 128, &L)
-                  : pick_launch(rm::k_render_bwd<GB>, *scene, true, 128, &L)) return e;
+  if (int e = kind == 1 ? pick_launch(rm::k_render_bwd<GB, 1>, *scene, true, 128, &L)
+            : kind == 2 ? pick_launch(rm::k_render_bwd<GB, 2>, *scene, true, 128, &L)
+                        : pick_launch(rm::k_render_bwd<GB, 0>, *scene, true, 128, &L)) return e;
   int64_t wave_tiles;
   {
     const int W = cam->width, rows = row_end - row_begin;
@@ -536,8 +536,9 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     a.hard_g = hard_ws + 10 * cap + (int64_t)steps * cap * 4;
     a.hard_pairs = reinterpret_cast<uint32_t*>(hard_ws + 10 * cap + (int64_t)steps * cap * 5);
   }
-  if (lap) rm::k_render_bwd<GB, true><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
-  else rm::k_render_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  if (kind == 1) rm::k_render_bwd<GB, 1><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  else if (kind == 2) rm::k_render_bwd<GB, 2><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  else rm::k_render_bwd<GB, 0><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
   int rows = grid;
   if (defer) {

@@ -1600,11 +1600,14 @@ struct DeferToList {
 };
 
 // VJP of the fused frame w.r.t. scene parameters (modes 0 and 4).
-// kLap: the Laplacian shader (mode 5).  Its global normalisation (shader.py:81-89: a division by the frame's largest
-// |Laplacian|, i.e. a reduction over every pixel -- and every rank of a row-tiled render) is differentiated by the
-// host; grad_image[..., 0] is then dL/d(surface_laplacian) of the ray, which goes into the five-tap Laplacian here.
-// A separate instantiation: the centre tap's VJP is a second inlined scene VJP the other modes should not carry.
-template <class Cfg, bool kLap = false>
+// kKind 0: the per-pixel shaders.  The globally normalised ones (modes 1, 2, 5: shader.py:27-38, 45-55, 81-89) have a
+// normalisation that is a reduction over every pixel -- and every rank of a row-tiled render; the host differentiates
+// it (ray_marching_amd/ops.py) and grad_image[..., 0] then is dL/d(un-normalised value) of the ray:
+//   mode 1 (kind 0): log(clamp(|origin - p|, 1e-2, inf)) -- no scene evaluation, handled among the per-pixel modes;
+//   kKind 2, mode 2: log(clamp(scene(p), 1e-2, inf)) -- one scene VJP at the surface point;
+//   kKind 1, mode 5: the five-tap Laplacian -- the four taps plus the centre.
+// Separate instantiations: each of the last two adds an inlined scene VJP the other modes should not carry.
+template <class Cfg, int kKind = 0>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
@@ -1631,8 +1634,16 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     V3 gn = mk3(0.0f, 0.0f, 0.0f);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
     float gq0 = 0.0f, gq1 = 0.0f, gq2 = 0.0f, gq3 = 0.0f;     // direct dependence of the shader on the pose quaternion
-    if constexpr (kLap) {
-      // nothing here: the upstream of this mode is on the Laplacian, not on the normal (normals_backward below)
+    V3 gp_direct = mk3(0.0f, 0.0f, 0.0f);        // mode 1: direct dependence of the shader on the surface point / the origin
+    if constexpr (kKind != 0) {
+      // nothing here: the upstream of these modes is on the Laplacian / on scene(p), not on the normal (below)
+    } else if (a.mode == RM_MODE_DISTANCE) {
+      // norm(origin - p).clamp(1e-2, inf).log(): grad / clamped, masked by the clamp, along (origin - p) / norm
+      const V3 o = qrot(load3(static_cast<const float*>(a.cam.ray_positions), gi), ps.w, ps.qv) + ps.t;
+      const V3 d = o - p;
+      const float dn = norm3(d);
+      const float gd = (dn >= 1e-2f) ? gi3.x / dn : 0.0f;
+      gp_direct = (dn == 0.0f) ? mk3(0.0f, 0.0f, 0.0f) : mk3(gd * (d.x / dn), gd * (d.y / dn), gd * (d.z / dn));   // dL/d(origin); dL/dp is its negative
     } else if (a.mode == RM_MODE_LAMBERTIAN) {
       float c = -dot_seq(v, n);
       float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
@@ -1715,13 +1726,21 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     int walked = 0;
     bool deferred = false;
     if (a.mode != RM_MODE_VIGNETTE) {            // the vignette does not depend on the surface at all
-      lam = normals_backward(scene, T, p, gn, kLap ? gi3.x : 0.0f, kLap);
+      if constexpr (kKind == 2) {                // proximity: scene(p).clamp(1e-2, inf).log()
+        const float dist = scene.eval(p);
+        lam = scene.vjp(p, (dist >= 1e-2f) ? gi3.x / dist : 0.0f);
+      } else if (kKind == 0 && a.mode == RM_MODE_DISTANCE) {
+        lam = neg(gp_direct);
+      } else {
+        lam = normals_backward(scene, T, p, gn, kKind == 1 ? gi3.x : 0.0f, kKind == 1);
+      }
       int ne = a.nexec ? a.nexec[li] : a.steps;
       lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
                           a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
     }
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
-    if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam);
+    if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam + gp_direct);
+    if (live && deferred && a.grad_pos && kKind == 0 && a.mode == RM_MODE_DISTANCE) store3(a.grad_pos, li, gp_direct);
     if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
@@ -1851,7 +1870,8 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
     const float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
     gv = gv + sumf * lam;
   }
-  if (valid && a.grad_pos) store3(a.grad_pos, li, lam);
+  // (distance shader: k_render_bwd left the shader's direct dependence on the origin there for the deferred rays)
+  if (valid && a.grad_pos) store3(a.grad_pos, li, a.mode == RM_MODE_DISTANCE ? lam + load3(a.grad_pos, li) : lam);
   if (valid && a.grad_dirs) store3(a.grad_dirs, li, gv);
 }
 

@@ -336,7 +336,26 @@ workspaces = _Workspaces()
 # fused frame
 # --------------------------------------------------------------------------
 _GLOBAL_MODES = (1, 2, 5)
-_FUSED_VJP_MODES = {0, 3, 4, 5, 6, 7}   # shader modes rm_render_backward differentiates through (1, 2: the reference's gradient is NaN)
+_FUSED_VJP_MODES = {0, 1, 2, 3, 4, 5, 6, 7}   # shader modes rm_render_backward differentiates through
+
+
+def minmax_normalisation_vjp(grad_image: torch.Tensor, logd: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    """VJP of the distance / proximity shaders' normalisation (shader.py:33-38, 51-55:
+    log_dists.sub(min).div(max.sub(min)).pow(1 / 2.33), expanded to three channels) in the order autograd walks it;
+    returns dL/d(log_dists) per ray.  The pixel of the minimum has x = 0 under the power, whose slope there is
+    infinite: inf - inf reaches the ray of the minimum and inf * 0 the ray of the maximum, in the reference as here,
+    and every parameter component those two rays reach gets a NaN gradient; the other rays' upstreams are finite."""
+    gamma = 1.0 / 2.33
+    gy = grad_image.sum(-1)
+    r = hi - lo
+    a = logd - lo
+    gx = gy * (gamma * (a / r).pow(gamma - 1.0))
+    ga = gx / r
+    gr = (-gx * a / (r * r)).sum()
+    gm = -ga.sum() - gr                   # both log_dists.min() nodes
+    top, bottom = logd == hi, logd == lo
+    zero = torch.zeros_like(ga)
+    return ga + torch.where(top, gr / top.sum(), zero) + torch.where(bottom, gm / bottom.sum(), zero)
 
 
 def laplacian_normalisation_vjp(grad_image: torch.Tensor, lap: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
@@ -424,7 +443,7 @@ class Render(torch.autograd.Function):
         first_pass = None
         if mode in _GLOBAL_MODES:
             # (a training frame of the Laplacian shader keeps the un-normalised values for its backward)
-            first_pass = image if (image_dtype == torch.float32 and not (record and mode == 5)) \
+            first_pass = image if (image_dtype == torch.float32 and not record) \
                 else torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev)
         regen = regen_applies(flags, steps, record)
         if not regen:
@@ -464,7 +483,7 @@ class Render(torch.autograd.Function):
                     globals()["fwd_last_work"] = minmax   # measurement runs (kernel_event_sink): the workspace words of this frame
             lohi = None
             if mode in _GLOBAL_MODES:
-                if allreduce_minmax is not None or (record and mode == 5):
+                if allreduce_minmax is not None or record:
                     lohi = torch.empty(2, dtype=torch.float32, device=dev)
                     _abi.check(_lib.rm_minmax_decode(_abi.ptr(minmax), _abi.ptr(lohi), stream), "rm_minmax_decode")
                 if allreduce_minmax is not None:
@@ -480,7 +499,7 @@ class Render(torch.autograd.Function):
             # (the backward kernels read the live storages, which must still hold the forward's values)
             ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
             # Laplacian shader: the un-normalised values and their largest magnitude, for the normalisation's VJP
-            ctx.lap = (first_pass, lohi, allreduce_minmax is not None) if mode == 5 else None
+            ctx.lap = (first_pass, lohi, allreduce_minmax is not None) if mode in _GLOBAL_MODES else None
             ctx.scene_keep = keep       # (program, packed block or None, pointer table or None): what backward reads through
             ctx.cs, ctx.tetra, ctx.steps, ctx.rows, ctx.flags = cs, tetra, steps, (r0, r1), flags
             ctx.precision, ctx.cmap, ctx.degree = precision, cmap, degree
@@ -495,12 +514,14 @@ class Render(torch.autograd.Function):
         prm, q, t, rp, rd, p_final, traj, nexec, *leaves = ctx.saved_tensors
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
-        if ctx.mode == 5:
-            lap3, lohi, across_ranks = ctx.lap
+        if ctx.mode in _GLOBAL_MODES:
+            # the normalisation over the whole frame is differentiated here; the kernels take dL/d(un-normalised value)
+            raw3, lohi, across_ranks = ctx.lap
             if across_ranks:
-                raise NotImplementedError("gradient of the Laplacian shader through a maximum taken across ranks")
-            glap = laplacian_normalisation_vjp(g, lap3[..., 0], lohi[1])
-            g = torch.stack([glap, torch.zeros_like(glap), torch.zeros_like(glap)], dim=-1).contiguous()
+                raise NotImplementedError("gradient of a globally normalised shader through a minimum / maximum taken across ranks")
+            graw = laplacian_normalisation_vjp(g, raw3[..., 0], lohi[1]) if ctx.mode == 5 \
+                else minmax_normalisation_vjp(g, raw3[..., 0], lohi[0], lohi[1])
+            g = torch.stack([graw, torch.zeros_like(graw), torch.zeros_like(graw)], dim=-1).contiguous()
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         lib = cs.lib(True, ctx.precision)
         with torch.cuda.device(dev):

@@ -563,9 +563,6 @@ def test_bad_calls_raise():
     with pytest.raises(RmError):
         loop(q, t, 0, 1, -1)                      # negative step count
     with pytest.raises(NotImplementedError):
-        loop.scene.sdfs[0].radius.requires_grad_(True)
-        loop(q, t, 1, 1, 8).sum().backward()      # no fused VJP for the distance shader
-    with pytest.raises(NotImplementedError):
         loop.shader(None, q, None, None, None, None, None, None, mode="lambertian", degree=1)
 
 
@@ -1088,12 +1085,15 @@ def test_fused_vjp_of_vignette_tangent_and_spin_shaders(mode, kernel_path):
         assert err <= 1e-4, (mode, pname, err)
 
 
+@pytest.mark.parametrize("mode", [5, 1, 2])
 @pytest.mark.parametrize("case", range(10))
-def test_fused_vjp_of_the_laplacian_shader(case):
-    """Mode 5 (shader.py:81-89): lap / max|lap| through clamp and x^(1/2.33).  The reference's gradient is finite
-    when the pixel of the largest |Laplacian| has a negative one, and NaN for every parameter when it has a positive
-    one (the clamped value is 0 there and the power has an infinite slope); both behaviours are reproduced -- scene
-    parameters and the pose against CPU autograd on the oracle."""
+def test_fused_vjp_of_the_globally_normalised_shaders(case, mode):
+    """Mode 5 (shader.py:81-89): lap / max|lap| through clamp and x^(1/2.33): the reference's gradient is finite
+    when the pixel of the largest |Laplacian| has a negative one, and NaN in every parameter component that pixel's
+    ray reaches when it has a positive one (the clamped value is 0 there and the power has an infinite slope).
+    Modes 1 and 2 (shader.py:27-55, normalised by the frame's minimum and maximum): the minimum pixel always is
+    x = 0, so the rays of the minimum and the maximum always carry NaN.  Both behaviours are reproduced: NaN patterns
+    element for element, finite components against CPU autograd on the oracle -- scene parameters and the pose."""
     h, w, steps = 40, 48, 48
     spec = O.scene_test1_closed() if case % 2 == 0 else O.scene_test2()
     bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
@@ -1103,25 +1103,25 @@ def test_fused_vjp_of_the_laplacian_shader(case):
     wimg = torch.rand(1, h, w, 3, generator=gen)
     spec_g = O.map_spec(spec, lambda x: x.clone().requires_grad_(True))
     qc, tc = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
-    (O.render(spec_g, bufs, qc, tc, 5, 1, steps, H.EPS) * wimg).mean().backward()
+    (O.render(spec_g, bufs, qc, tc, mode, 1, steps, H.EPS) * wimg).mean().backward()
     module = H.spec_to_module(spec)
     loop = H.make_loop(module, h, w)
     qg, tg = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
-    img = loop(qg, tg, 5, 1, steps)
+    img = loop(qg, tg, mode, 1, steps)
     (img * wimg.to(DEV)).mean().backward()
     wants = [(n, p.grad) for n, p in O.spec_parameters(spec_g)] + [("orientation", qc.grad), ("translation", tc.grad)]
     gots = [p.grad for _, p in module.named_parameters()] + [qg.grad, tg.grad]
     ref_nan = any(wg is not None and torch.isnan(wg).any() for _, wg in wants)
-    print(f"case {case}: reference gradient {'NaN' if ref_nan else 'finite'}")
+    print(f"mode {mode} case {case}: reference gradient {'NaN' if ref_nan else 'finite'}")
     for (name, want), got in zip(wants, gots):
         if want is None:
             assert got is None or float(got.abs().max()) == 0.0, name
             continue
         got = got.cpu()
         # (a NaN reference gradient leaves exact zeros where no ray reaches a parameter component: the same here)
-        assert torch.equal(torch.isnan(want), torch.isnan(got)), (case, name, want, got)
+        assert torch.equal(torch.isnan(want), torch.isnan(got)), (mode, case, name, want, got)
         fin = ~torch.isnan(want)
         if fin.any():
             scale = max(1.0, want[fin].abs().max().item())
             err = (got[fin] - want[fin]).abs().max().item()
-            assert err <= 2e-4 * scale, (case, name, err, scale)
+            assert err <= 2e-4 * scale, (mode, case, name, err, scale)
