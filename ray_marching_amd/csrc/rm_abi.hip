@@ -498,7 +498,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   if (cam->dtype != RM_DTYPE_F32) return fail(RM_E_BADARG, "rm_render_backward: fp32 camera buffers only");
   const bool mapped = (mode == RM_MODE_TANGENT || mode == RM_MODE_SPIN);
   if (mode < 0 || mode > 7) return fail(RM_E_BADARG, "rm_render_backward: mode %d not in 0..7", mode);
-  const int kind = (mode == RM_MODE_LAPLACIAN) ? 1 : (mode == RM_MODE_PROXIMITY ? 2 : 0);
+  const int kind = (mode == RM_MODE_LAPLACIAN) ? 1 : (mode == RM_MODE_PROXIMITY ? 2 : (mode == RM_MODE_DISTANCE ? 3 : 0));
   if (mapped && (!cmap || cmap_size <= 0 || cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64))
     return fail(RM_E_BADARG, "rm_render_backward: mode %d needs the colormap of the forward call", mode);
   if (!p_final || !grad_image || !partials || (steps > 0 && !traj)) return fail(RM_E_BADARG, "rm_render_backward: null buffer");
@@ -514,6 +514,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   Launch L;
   if (int e = kind == 1 ? pick_launch(rm::k_render_bwd<GB, 1>, *scene, true, 128, &L)
             : kind == 2 ? pick_launch(rm::k_render_bwd<GB, 2>, *scene, true, 128, &L)
+            : kind == 3 ? pick_launch(rm::k_render_bwd<GB, 3>, *scene, true, 128, &L)
                         : pick_launch(rm::k_render_bwd<GB, 0>, *scene, true, 128, &L)) return e;
   int64_t wave_tiles;
   {
@@ -538,6 +539,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   }
   if (kind == 1) rm::k_render_bwd<GB, 1><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   else if (kind == 2) rm::k_render_bwd<GB, 2><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  else if (kind == 3) rm::k_render_bwd<GB, 3><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   else rm::k_render_bwd<GB, 0><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
   int rows = grid;

@@ -1603,10 +1603,11 @@ struct DeferToList {
 // kKind 0: the per-pixel shaders.  The globally normalised ones (modes 1, 2, 5: shader.py:27-38, 45-55, 81-89) have a
 // normalisation that is a reduction over every pixel -- and every rank of a row-tiled render; the host differentiates
 // it (ray_marching_amd/ops.py) and grad_image[..., 0] then is dL/d(un-normalised value) of the ray:
-//   mode 1 (kind 0): log(clamp(|origin - p|, 1e-2, inf)) -- no scene evaluation, handled among the per-pixel modes;
+//   kKind 3, mode 1: log(clamp(|origin - p|, 1e-2, inf)) -- no scene evaluation, but three more live registers;
 //   kKind 2, mode 2: log(clamp(scene(p), 1e-2, inf)) -- one scene VJP at the surface point;
 //   kKind 1, mode 5: the five-tap Laplacian -- the four taps plus the centre.
-// Separate instantiations: each of the last two adds an inlined scene VJP the other modes should not carry.
+// Separate instantiations: kinds 1 and 2 add an inlined scene VJP, and kind 3 inside kind 0 cost the training step's
+// backward kernel 43 % (116 -> 166 us: registers across the reverse march) -- the per-pixel modes carry none of it.
 template <class Cfg, int kKind = 0>
 __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
@@ -1634,16 +1635,16 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     V3 gn = mk3(0.0f, 0.0f, 0.0f);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
     float gq0 = 0.0f, gq1 = 0.0f, gq2 = 0.0f, gq3 = 0.0f;     // direct dependence of the shader on the pose quaternion
-    V3 gp_direct = mk3(0.0f, 0.0f, 0.0f);        // mode 1: direct dependence of the shader on the surface point / the origin
-    if constexpr (kKind != 0) {
-      // nothing here: the upstream of these modes is on the Laplacian / on scene(p), not on the normal (below)
-    } else if (a.mode == RM_MODE_DISTANCE) {
+    [[maybe_unused]] V3 gp_direct = mk3(0.0f, 0.0f, 0.0f);   // kind 3: direct dependence of the shader on the origin (- on the surface point)
+    if constexpr (kKind == 3) {
       // norm(origin - p).clamp(1e-2, inf).log(): grad / clamped, masked by the clamp, along (origin - p) / norm
       const V3 o = qrot(load3(static_cast<const float*>(a.cam.ray_positions), gi), ps.w, ps.qv) + ps.t;
       const V3 d = o - p;
       const float dn = norm3(d);
       const float gd = (dn >= 1e-2f) ? gi3.x / dn : 0.0f;
-      gp_direct = (dn == 0.0f) ? mk3(0.0f, 0.0f, 0.0f) : mk3(gd * (d.x / dn), gd * (d.y / dn), gd * (d.z / dn));   // dL/d(origin); dL/dp is its negative
+      gp_direct = (dn == 0.0f) ? mk3(0.0f, 0.0f, 0.0f) : mk3(gd * (d.x / dn), gd * (d.y / dn), gd * (d.z / dn));
+    } else if constexpr (kKind != 0) {
+      // nothing here: the upstream of these modes is on the Laplacian / on scene(p), not on the normal (below)
     } else if (a.mode == RM_MODE_LAMBERTIAN) {
       float c = -dot_seq(v, n);
       float g = (c >= 0.0f && c <= 1.0f) ? ((gi3.x + gi3.y) + gi3.z) : 0.0f;   // expand(-1,H,W,3) sums channels
@@ -1729,7 +1730,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
       if constexpr (kKind == 2) {                // proximity: scene(p).clamp(1e-2, inf).log()
         const float dist = scene.eval(p);
         lam = scene.vjp(p, (dist >= 1e-2f) ? gi3.x / dist : 0.0f);
-      } else if (kKind == 0 && a.mode == RM_MODE_DISTANCE) {
+      } else if constexpr (kKind == 3) {
         lam = neg(gp_direct);
       } else {
         lam = normals_backward(scene, T, p, gn, kKind == 1 ? gi3.x : 0.0f, kKind == 1);
@@ -1739,8 +1740,11 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
                           a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
     }
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
-    if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam + gp_direct);
-    if (live && deferred && a.grad_pos && kKind == 0 && a.mode == RM_MODE_DISTANCE) store3(a.grad_pos, li, gp_direct);
+    if constexpr (kKind == 3) {
+      if (live && a.grad_pos) store3(a.grad_pos, li, deferred ? gp_direct : lam + gp_direct);   // (deferred: k_bwd_hard_a adds its part)
+    } else {
+      if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam);
+    }
     if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
