@@ -275,3 +275,19 @@ def test_auto_mode_inside_a_user_graph_capture():
         g.replay()
         torch.cuda.synchronize()
     assert _same_bits(img, want)
+
+
+def test_regen_in_a_band_only_loop():
+    """RenderLoop(rows=band) -- what a rank of a row-tiled render builds: it holds only its band of the camera
+    buffers -- with the pool kernels == the same rows of the whole frame from the tile kernel."""
+    n, h, w, steps = 1, 520, 536, 32
+    band = (136, 424)
+    q, t = _poses(n, 1.0, 13)
+    whole = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0)
+    pool = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=True, adaptive_order=2, rows=band)
+    assert pool.camera.ray_positions.shape[1] == band[1] - band[0]
+    for mode in (4, 1, 7):
+        with torch.no_grad():
+            want = whole(q, t, mode, 1, steps, rows=band) if mode == 1 else whole(q, t, mode, 1, steps)[:, band[0]:band[1]]
+            for frame in range(3):
+                assert _same_bits(pool(q, t, mode, 1, steps), want), (mode, frame)
