@@ -351,6 +351,7 @@ class RenderLoop(nn.Module):
         """HIP-graph replay of one inference frame (see CapturedFrame)."""
         return CapturedFrame(self, mode, degree, marching_steps, rows)
 
+    @torch.compiler.disable      # main.py:44 wraps the loop in torch.compile: Dynamo steps over the ctypes launches (eager bits, no Inductor kernel)
     def forward(self, orientations: Tensor, translations: Tensor, mode: int = 0, degree: int = 1,
                 marching_steps: int = 32, rows=None, allreduce_minmax=None, tile_order=None, tile_cost=None):
         """-> image [N, H, W, 3] in the module's dtype (modes 6, 7: promoted with the colormap's, float64 for

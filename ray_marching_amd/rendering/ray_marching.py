@@ -50,14 +50,17 @@ class PinholeCamera(nn.Module):
         if rows is not None:
             origins = origins[:, self.rows[0]:self.rows[1]].contiguous()
             directions = directions[:, self.rows[0]:self.rows[1]].contiguous()
-        # buffer names follow the reference so state_dicts interchange
-        self.register_buffer("focus", focus.view(1, 1, 1, 3).expand(num_cameras, 1, 1, 3))
+        # buffer names follow the reference so state_dicts interchange.  The reference registers `focus`, `theta` and
+        # `pixel_frames` as expanded (overlapping) views, which load_state_dict cannot write into once
+        # num_cameras > 1; here they own their memory, so a reference checkpoint loads for any N.
+        self.register_buffer("focus", focus.view(1, 1, 1, 3).expand(num_cameras, 1, 1, 3).clone())
         self.register_buffer("theta", theta)
         self.register_buffer("ray_positions", origins)
         self.register_buffer("ray_directions", directions)
-        self.register_buffer("pixel_frames", torch.eye(3)[None, None, None, :2, :].expand(num_cameras, 1, 1, 2, 3))
+        self.register_buffer("pixel_frames", torch.eye(3)[None, None, None, :2, :].expand(num_cameras, 1, 1, 2, 3).clone())
         self.quaternion_to_so3 = QuaternionToSO3()
 
+    @torch.compiler.disable
     def forward(self, orientation: Tensor, translation: Tensor):
         pos, frames, dirs = ops.camera_forward(self.ray_positions, self.ray_directions, orientation, translation)
         return (pos, frames, pos, dirs)
@@ -74,6 +77,7 @@ class SDFMarcher(nn.Module):
         self.sdf_scene = sdf_scene
         self.early_out = early_out
 
+    @torch.compiler.disable
     def forward(self, ray_positions: Tensor, ray_directions: Tensor, marching_steps: int = 32) -> Tensor:
         cs = compiled_for(self.sdf_scene)
         return ops.March.apply(ops.live_params(cs, ray_positions.device, ray_positions, ray_directions), ray_positions, ray_directions, cs,
@@ -110,6 +114,7 @@ class SDFNormals(nn.Module):
             self._tetra = (key, ops.make_tetra(self.offsets, self.offsets_inverse, self.normals_eps))
         return self._tetra[1]
 
+    @torch.compiler.disable
     def forward(self, surface_coords: Tensor):
         cs = compiled_for(self.sdf_scene)
         return ops.Normals.apply(ops.live_params(cs, surface_coords.device, surface_coords), surface_coords, cs, self.tetra())

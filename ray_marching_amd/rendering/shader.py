@@ -162,6 +162,7 @@ def _differentiable(*tensors):
 
 
 class LambertianShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, ray_directions: Tensor, surface_normals: Tensor) -> Tensor:
         if _differentiable(ray_directions, surface_normals):
             return _PixelShade.apply(ray_directions, surface_normals, None, 0)
@@ -169,18 +170,21 @@ class LambertianShader(nn.Module):
 
 
 class DistanceShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, px_coords: Tensor, surface_coords: Tensor) -> Tensor:
         _no_grad_inputs(px_coords, surface_coords)
         return shade(1, px_coords=px_coords, coords=surface_coords)
 
 
 class ProximityShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, surface_distances: Tensor) -> Tensor:
         _no_grad_inputs(surface_distances)
         return shade(2, dist=surface_distances)
 
 
 class VignetteShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, ray_directions: Tensor, pixel_frames: Tensor) -> Tensor:
         if _differentiable(ray_directions):
             return _PixelShade.apply(ray_directions, None, pixel_frames, 3)
@@ -188,6 +192,7 @@ class VignetteShader(nn.Module):
 
 
 class NormalShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, surface_normals: Tensor) -> Tensor:
         if _differentiable(surface_normals):
             return _PixelShade.apply(None, surface_normals, None, 4)
@@ -195,6 +200,7 @@ class NormalShader(nn.Module):
 
 
 class LaplacianShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, surface_laplacian: Tensor) -> Tensor:
         _no_grad_inputs(surface_laplacian)
         return shade(5, lap=surface_laplacian)
@@ -206,6 +212,7 @@ def _orientation_from_conj(camera_orientation_conj: Tensor) -> Tensor:
 
 
 class TangentShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, camera_orientation_conj: Tensor, ray_directions: Tensor, surface_normals: Tensor,
                 cyclic_colourmap: Tensor, degree: int = 1) -> Tensor:
         _no_grad_inputs(ray_directions, surface_normals)
@@ -214,6 +221,7 @@ class TangentShader(nn.Module):
 
 
 class SpinShader(nn.Module):
+    @torch.compiler.disable
     def forward(self, camera_orientation_conj: Tensor, surface_normals: Tensor, cyclic_colourmap: Tensor,
                 degree: int = 1) -> Tensor:
         _no_grad_inputs(surface_normals)
@@ -236,6 +244,7 @@ class Shader(nn.Module):
         self.vignette_shader = VignetteShader()
         self.laplacian_layer = LaplacianShader()
 
+    @torch.compiler.disable
     def forward(self, px_coords: Tensor, camera_orientation: Tensor, pixel_frames: Tensor, ray_directions: Tensor,
                 surface_coords: Tensor, surface_normals: Tensor, surface_laplacian: Tensor,
                 surface_distances: Tensor, mode: int, degree: int) -> Tensor:

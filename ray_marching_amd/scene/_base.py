@@ -1,6 +1,7 @@
 """Common base of the SDF nodes: forward() = compile the subtree, run the HIP evaluator."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 from torch import Tensor
 
@@ -17,7 +18,19 @@ class SDFNode(nn.Module):
     _rm_kind = None
 
     def forward(self, query_positions: Tensor) -> Tensor:
-        if query_positions.shape[-1] != 3:
-            raise ValueError(f"query_positions must be [..., 3], got {tuple(query_positions.shape)}")
+        return self._evaluate(query_positions)
+
+    @torch.compiler.disable      # under torch.compile (main.py:44) the launch stays the eager ctypes call
+    def _evaluate(self, points: Tensor) -> Tensor:
+        if points.shape[-1] != 3:
+            raise ValueError(f"query points must be [..., 3], got {tuple(points.shape)}")
         cs = compiled_for(self)
-        return SDFEval.apply(live_params(cs, query_positions.device, query_positions), query_positions, cs)
+        return SDFEval.apply(live_params(cs, points.device, points), points, cs)
+
+
+class SDFCoordsNode(SDFNode):
+    """The four combinators whose ``forward`` names its argument ``query_coords`` in the reference
+    (scene/transformations.py:67, 90, 117, 131), so ``sdf(query_coords=p)`` works here as there."""
+
+    def forward(self, query_coords: Tensor) -> Tensor:
+        return self._evaluate(query_coords)

@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ._base import SDFNode
+from ._base import SDFCoordsNode, SDFNode
 
 
 def _param(value):
@@ -23,7 +23,7 @@ class SDFAffineTransformation(SDFNode):
         self.orientation = _param(orientation)
 
 
-class SDFSmoothUnion(SDFNode):
+class SDFSmoothUnion(SDFCoordsNode):
     """-logsumexp(-k d_i) / k over the children."""
     _rm_kind = "smooth_union"
 
@@ -33,7 +33,7 @@ class SDFSmoothUnion(SDFNode):
         self.blend_k = _param(blend_k)
 
 
-class SDFUnion(SDFNode):
+class SDFUnion(SDFCoordsNode):
     """min over the children."""
     _rm_kind = "union"
 
@@ -42,7 +42,7 @@ class SDFUnion(SDFNode):
         self.sdfs = nn.ModuleList(sdfs)
 
 
-class SDFRounding(SDFNode):
+class SDFRounding(SDFCoordsNode):
     """d - rounding."""
     _rm_kind = "rounding"
 
@@ -52,7 +52,7 @@ class SDFRounding(SDFNode):
         self.rounding = _param(rounding)
 
 
-class SDFOnion(SDFNode):
+class SDFOnion(SDFCoordsNode):
     """|d| - radius (a shell of the child)."""
     _rm_kind = "onion"
 

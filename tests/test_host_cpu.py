@@ -497,3 +497,17 @@ def test_auto_kernel_choice_survives_a_host_far_ahead_of_the_gpu():
             if frame - f0 >= 40:
                 ev.ready = True
     assert loop._choice_state["k"]["regen"] is True and len(loop._choice_state["k"]["log"]) >= 2
+
+
+def test_torch_compile_steps_over_the_ctypes_launch():
+    """main.py:44 wraps the RenderLoop in torch.compile(mode='max-autotune').  The forwards are marked
+    torch.compiler.disable, so Dynamo does not trace into the ctypes call: the eager code runs -- seen here, without a
+    GPU, by the eager path's own refusal of CPU tensors arriving through the compiled wrapper."""
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    loop = torch.compile(RenderLoop(make_test_scene2(), px_width=16, px_height=8), mode="max-autotune")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loop(torch.tensor([[1.0, 0.0, 0.0, 0.0]]), torch.zeros(1, 3), 0, 1, 32)
+    scene = torch.compile(make_test_scene2())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scene(torch.zeros(4, 3))
