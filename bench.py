@@ -9,10 +9,14 @@ RenderLoop.forward, i.e. the fused HIP kernel k_render_fwd (camera -> 128 march 
 -> distance -> tetrahedral normals -> shader).  Camera buffers, scene parameters and output
 images are resident in HBM before the timed region; nothing crosses PCIe inside it.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling by pixel-row tiles.
-The frame is 1920 x (1080*N); rank r renders rows [1080 r, 1080 (r+1)) -- holding only that band of the camera
-buffers -- and the tiles reach rank 0 as point-to-point transfers (one xGMI link per peer, all in flight
-together) on a side stream, overlapped with the next frame's render.
+N > 1, one rank per GPU over RCCL: started by torch.distributed.run (RANK / WORLD_SIZE in the environment), or --
+a plain `python bench.py --gpus N` -- by this script itself, which starts the N ranks as fresh child processes
+BEFORE it makes any GPU call, relays rank 0's JSON line and exits non-zero if a rank fails or the node has fewer
+than N GPUs.  Weak scaling: the job is an N-camera batch of the config-2 frame (the reference's `num_cameras`,
+control.py:201), one 1920x1080 camera per rank at the same pose, so every rank does EQUAL work; the frames reach
+rank 0 as point-to-point transfers (one xGMI link per peer, all in flight together) on a side stream, overlapped with
+the next frame's render.  `--weak-mode tall` is the round-2 variant: one 1920 x (1080*N) frame at fixed focal length,
+rank r renders rows [1080 r, 1080 (r+1)) -- bands see different content, i.e. unequal work per rank.
 
 `--config 5` times BASELINE configs[4] instead: the 7680x4320 frame of the 32-primitive smooth-union scene at 256
 steps, STRONG scaling over row bands (N = 1 renders all 8 bands itself).
@@ -65,6 +69,11 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=[2, 5], help="2: headline (configs[1]); 5: configs[4], strong scaling")
     ap.add_argument("--exchange", default="p2p", choices=["p2p", "gather"], help="N>1 tile exchange: batch_isend_irecv or dist.gather")
     ap.add_argument("--skip-config3", action="store_true", help="skip the secondary 3840x2160x256 fp16 measurement")
+    ap.add_argument("--weak-mode", default="cameras", choices=["cameras", "tall"],
+                    help="N>1, config 2: one camera of an N-camera batch per rank (equal work, default) or row bands of one tall frame")
+    ap.add_argument("--stub-render", action="store_true",
+                    help="launcher / collective rehearsal without a GPU: a host stand-in replaces the HIP RenderLoop; the line is marked stub")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank raises before the first barrier
     ap.add_argument("--graph-leg", action="store_true", help=argparse.SUPPRESS)   # child process of the backward probe
     return ap.parse_args()
 
@@ -354,102 +363,204 @@ def exchange_tile(dist, args, pay, gathered_j, rank, world, device):
         r.wait()
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run,
+    rendezvous on 127.0.0.1) before this process has made any GPU call -- never by replacing a process that has
+    touched the GPU --, relay rank 0's JSON line, return non-zero when a rank failed or no line came back."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not (args.share_gpu or args.stub_render):
+        have = torch.cuda.device_count()            # counts devices without initialising the GPU
+        if have < n:
+            log(f"--gpus {n} but this node shows {have} GPU(s); use --share-gpu only for single-GPU rehearsals")
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's peer mappings need it on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    log(f"self-launch: {n} ranks via torch.distributed.run on 127.0.0.1:{port}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)     # stderr passes through
+    line = None
+    for raw in proc.stdout:
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw
+        elif raw:
+            print(raw, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        log(f"self-launch: torch.distributed.run exited with {rc} (a rank failed)")
+        return rc
+    if line is None:
+        log("self-launch: the ranks finished without a result line")
+        return 3
+    print(line, flush=True)
+    return 0
+
+
+class StubLoop:
+    """--stub-render: host stand-in for the HIP RenderLoop, so that the launcher, the process group, the barriers,
+    the tile exchange and the JSON line can be rehearsed (and tested) on a machine without a GPU.  It renders nothing;
+    the result line says so."""
+    regen, _choice_state = False, {}
+
+    def __init__(self, height, width):
+        self.h, self.w = height, width
+
+    def __call__(self, q, t, mode, degree, steps, rows=None):
+        r0, r1 = rows if rows is not None else (0, self.h)
+        return torch.full((1, r1 - r0, self.w, 3), float(mode))
+
+
 def main():
     args = parse()
     if args.graph_leg:
         return graph_leg()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
-    torch.cuda.set_device(dev)
+    stub = args.stub_render
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if not args.share_gpu and torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; --share-gpu rehearses on one)")
+        dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == args.stub_fail_rank:
+            raise SystemExit(f"rank {rank}: failing on request (--stub-fail-rank)")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        world = dist.get_world_size()          # n_gpus of the line = what the backend really initialised
 
-    from ray_marching_amd.scene.scene_registry import make_closed_test_scene, make_many_primitive_scene, make_test_scene2
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
     config5 = args.config == 5
-    make_scene = (lambda: make_many_primitive_scene(32)) if config5 else make_test_scene2
+    from ray_marching_amd.distributed import GREY_MODES, row_band, tile_payload
+    if not stub:
+        from ray_marching_amd.scene.scene_registry import make_closed_test_scene, make_many_primitive_scene, make_test_scene2
+        make_scene = (lambda: make_many_primitive_scene(32)) if config5 else make_test_scene2
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build_library()
-        if os.environ.get("RM_SPECIALIZE", "auto") != "off":
-            # the per-scene libraries of the benchmark scenes (no-op when __graft_entry__.build() made them;
-            # ~10 s of hipcc each on a fresh checkout, where the "auto" policy would otherwise time the
-            # interpreter while the library builds in the background).  Built on rank 0 only, behind a barrier.
-            from ray_marching_amd import specialize
-            from ray_marching_amd.compiler import compile_scene
-            try:
-                specialize.build(compile_scene(make_scene()), precision=args.precision)
-                if not args.skip_backward and not config5:
-                    specialize.build(compile_scene(make_closed_test_scene()))
-            except Exception as e:      # noqa: BLE001  (no hipcc: the interpreter still renders the frame)
-                log(f"specialised libraries not built: {e}")
+        import __graft_entry__ as entry
+        if rank == 0:
+            entry.build_library()
+            if os.environ.get("RM_SPECIALIZE", "auto") != "off":
+                # the per-scene libraries of the benchmark scenes (no-op when __graft_entry__.build() made them;
+                # ~10 s of hipcc each on a fresh checkout, where the "auto" policy would otherwise time the
+                # interpreter while the library builds in the background).  Built on rank 0 only, behind a barrier.
+                from ray_marching_amd import specialize
+                from ray_marching_amd.compiler import compile_scene
+                try:
+                    specialize.build(compile_scene(make_scene()), precision=args.precision)
+                    if not args.skip_backward and not config5:
+                        specialize.build(compile_scene(make_closed_test_scene()))
+                except Exception as e:      # noqa: BLE001  (no hipcc: the interpreter still renders the frame)
+                    log(f"specialised libraries not built: {e}")
     if dist is not None:
         dist.barrier()
 
-    from ray_marching_amd.control import RenderLoop
-    from ray_marching_amd.compiler import compiled_for
-    from ray_marching_amd.distributed import GREY_MODES, row_band, tile_payload
-
+    tile_w, tile_h = (W, H_TILE) if not stub else (96, 54)
     if config5:       # BASELINE configs[4]: one 7680x4320 frame, strong scaling over row bands
-        width, h_total, march, modes, cam_z = 7680, 4320, 256, (4,), -4.5
+        width, h_total, march, modes, cam_z = (7680, 4320, 256, (4,), -4.5) if not stub else (96, 54, 256, (4,), -4.5)
         band = row_band(h_total, rank, world)
         focal, sensor_h = PX * h_total, PX * h_total
-    else:             # BASELINE configs[1] per GPU, weak scaling: the frame grows with N
-        width, h_total, march, modes, cam_z = W, H_TILE * world, STEPS_MARCH, MODES, args.camera_z
-        band = (rank * H_TILE, (rank + 1) * H_TILE)
-        focal, sensor_h = PX * H_TILE, PX * h_total
-    # every rank holds only ITS band of the camera buffers (RenderLoop(rows=...))
-    def make_loop(**kw):
-        return RenderLoop(make_scene(), num_cameras=1, px_width=width, px_height=h_total, focal_length=focal,
-                          sensor_width=PX * width, sensor_height=sensor_h, normals_eps=EPS,
-                          early_out=not args.no_early_out, tile8x8=not args.linear_waves,
-                          dynamic_tiles=not args.static_tiles, precision=args.precision,
-                          rows=None if world == 1 else band, **kw).to(dev)
+        work_per_rank = "row bands of one frame: unequal (the bands see different parts of the scene)" if world > 1 else "whole frame"
+    elif args.weak_mode == "tall" and world > 1:
+        # round-2 weak scaling: ONE frame of 1080*N rows at fixed focal length; the bands see different content
+        width, h_total, march, modes, cam_z = tile_w, tile_h * world, STEPS_MARCH, MODES, args.camera_z
+        band = (rank * tile_h, (rank + 1) * tile_h)
+        focal, sensor_h = PX * tile_h, PX * h_total
+        work_per_rank = "unequal (row bands of one taller frame at fixed focal length: top/bottom bands are mostly ceiling/floor)"
+    else:
+        # BASELINE configs[1] per GPU, weak scaling over a camera batch (the reference's num_cameras): every rank
+        # renders one whole 1920x1080 camera at the same pose -> equal work; rank 0 collects the [N,H,W,C] batch
+        width, h_total, march, modes, cam_z = tile_w, tile_h, STEPS_MARCH, MODES, args.camera_z
+        band = (0, tile_h)
+        focal, sensor_h = PX * tile_h, PX * tile_h
+        work_per_rank = "equal (one 1920x1080 camera of an N-camera batch per rank, same pose)"
+    banded = world > 1 and band != (0, h_total)          # the rank holds only ITS band of the camera buffers
+
+    if stub:
+        def make_loop(**kw):
+            return StubLoop(h_total, width)
+        specialised = False
+    else:
+        from ray_marching_amd.control import RenderLoop
+        from ray_marching_amd.compiler import compiled_for
+
+        def make_loop(**kw):
+            return RenderLoop(make_scene(), num_cameras=1, px_width=width, px_height=h_total, focal_length=focal,
+                              sensor_width=PX * width, sensor_height=sensor_h, normals_eps=EPS,
+                              early_out=not args.no_early_out, tile8x8=not args.linear_waves,
+                              dynamic_tiles=not args.static_tiles, precision=args.precision,
+                              rows=band if banded else None, **kw).to(dev)
     loop = make_loop()
-    specialised = compiled_for(loop.scene).specialised
-    rows = None if world > 1 else (band if not config5 else None)
+    if not stub:
+        specialised = compiled_for(loop.scene).specialised
+    rows = band if (stub and banded) else None          # a band loop renders its band by default
     band_rows = band[1] - band[0]
     q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
     t = torch.tensor([[0.0, 0.0, cam_z]], device=dev)
-    rays_per_frame = width * (H_TILE if not config5 else h_total)      # per GPU (weak) / whole frame (strong)
+    rays_per_frame = width * (tile_h if not config5 else h_total)      # per GPU (weak) / whole frame (strong)
 
     gather = dist is not None and not args.no_gather
-    comm = torch.cuda.Stream(device=dev) if gather else None
+    comm = torch.cuda.Stream(device=dev) if (gather and not stub) else None
     gathered = None
-    per = -(-h_total // world) if config5 else H_TILE
+    per = -(-h_total // world) if config5 else tile_h
     if gather and rank == 0:
-        # grey shaders are one value in three channels: they cross xGMI as one channel (distributed.py)
-        gathered = [[torch.empty(1, per, width, 1 if m in GREY_MODES else 3, device=dev) for _ in range(world)]
-                    for m in modes]
+        # ONE preallocated buffer per frame kind; rank r's tile is received straight into rows [r*per, (r+1)*per)
+        # (contiguous views: no concatenation pass).  Grey shaders are one value in three channels: they cross xGMI as
+        # one channel (distributed.py)
+        gathered = []
+        for m in modes:
+            whole = torch.empty(1, per * world, width, 1 if m in GREY_MODES else 3, device=dev)
+            gathered.append([whole[:, r * per:(r + 1) * per] for r in range(world)])
 
     kernel_ms = []
 
     def one_step(timed):
-        from ray_marching_amd import ops
+        if not stub:
+            from ray_marching_amd import ops
         for j, mode in enumerate(modes):
             # HIP events on the launch stream immediately around the k_render_fwd launch (ops.Render.run)
-            ops.kernel_event_sink = kernel_ms if timed else None
+            if not stub:
+                ops.kernel_event_sink = kernel_ms if timed else None
             img = loop(q, t, mode, 1, march, rows=rows)
-            ops.kernel_event_sink = None
+            if not stub:
+                ops.kernel_event_sink = None
             if gather:
+                pay_of = lambda: tile_payload(img, mode)
+                if stub:
+                    pay = pay_of()
+                    if pay.shape[1] != per:
+                        pay = torch.cat([pay, pay.new_zeros((1, per - pay.shape[1], width, pay.shape[3]))], dim=1)
+                    exchange_tile(dist, args, pay, gathered[j] if rank == 0 else None, rank, world, dev)
+                    continue
                 done = torch.cuda.Event()
                 done.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
                     img.record_stream(comm)
-                    pay = tile_payload(img, mode)
+                    pay = pay_of()
                     if pay.shape[1] != per:      # ragged last band of a strong-scaling split
                         pay = torch.cat([pay, pay.new_zeros((1, per - pay.shape[1], width, pay.shape[3]))], dim=1)
                     exchange_tile(dist, args, pay, gathered[j] if rank == 0 else None, rank, world, dev)
@@ -457,19 +568,19 @@ def main():
     def timed_block():
         if comm is not None:
             torch.cuda.current_stream().wait_stream(comm)
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step(True)
         if comm is not None:
             torch.cuda.current_stream().wait_stream(comm)
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
         if dist is not None:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -489,7 +600,16 @@ def main():
     frame_rays = rays_per_frame * (world if not config5 else 1)   # rays of the whole job's frame
     value = frame_rays * len(modes) * args.steps / elapsed / 1e6
 
-    if rank == 0:
+    if rank == 0 and stub:
+        # launcher / collective rehearsal: nothing was rendered, so there is no rate and no roofline to report
+        print(json.dumps({"metric": "STUB: launcher rehearsal, no rendering (bench.py --stub-render)", "stub": True,
+                          "value": None, "unit": "Mrays/s", "n_gpus": world, "requested_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "scaling": "strong" if config5 else "weak", "data": "none (host stand-in for the renderer)",
+                          "config": {"workload": "stub", "backend": args.backend, "exchange": args.exchange,
+                                     "work_per_rank": work_per_rank, "band": list(band),
+                                     "gathered_rows": None if gathered is None else per * world}}), flush=True)
+    elif rank == 0:
         launch_rays = width * band_rows if world > 1 else rays_per_frame
         evals = launch_rays * (march + 6)
         ach_gbs = launch_rays * BYTES_PER_RAY / (per_launch_ms * 1e-3) / 1e9
@@ -523,7 +643,8 @@ def main():
         out = {
             "metric": "Mrays/sec at 1920x1080x128 iters; fwd+bwd ms/frame" if not config5
                       else "Mrays/sec at 7680x4320x256 iters, 32-primitive scene (BASELINE configs[4])",
-            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "requested_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if config5 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -539,7 +660,10 @@ def main():
                        "early_out": not args.no_early_out, "wave_tile": "64x1" if args.linear_waves else "8x8", "arithmetic": args.precision,
                        "tile_schedule": "static stride" if args.static_tiles else "64 atomic queues + stealing",
                        "kernels": "per-scene specialised (StaticCfg)" if specialised else "generic LDS interpreter",
-                       "parallelism": f"row-tiles x{world}" + (f" + {args.exchange} tile exchange to rank 0" if gather else "")},
+                       "parallelism": (f"row-tiles x{world}" if (config5 or banded) else f"camera batch x{world}")
+                                      + (f" + {args.exchange} tile exchange to rank 0" if gather else ""),
+                       "work_per_rank": work_per_rank,
+                       "backend": None if dist is None else ("rccl" if args.backend == "nccl" else args.backend)},
             "ray_sdf_evals_per_s": value * 1e6 * (march + 6),
             "roofline": roof,
         }

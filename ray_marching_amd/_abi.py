@@ -16,7 +16,7 @@ import torch  # noqa: F401,E402
 
 ABI_VERSION = 10
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librm_hip.so")
+from ._build import LIB_PATH  # noqa: E402  (ray_marching_amd/lib/librm_hip.so, or under RM_LIB_DIR)
 
 # opcodes (include/rm_abi.h)
 OP_SPHERE, OP_BOX, OP_PLANE, OP_LINE, OP_DISK, OP_TORUS = 1, 2, 3, 4, 5, 6

@@ -10,7 +10,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIBDIR = os.path.join(_HERE, "lib")
+# RM_LIB_DIR: build into / load from another directory (variant builds of tests and A/B probes: the product library
+# under ray_marching_amd/lib/ is then never replaced)
+LIBDIR = os.environ.get("RM_LIB_DIR") or os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIBDIR, "librm_hip.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("rm_abi.hip", "rm_kernels.h", "rm_device.h", "rm_math.h")] + \
     [os.path.join(os.path.dirname(_HERE), "include", "rm_abi.h")]

@@ -164,6 +164,12 @@ class RenderLoop(nn.Module):
         # (which rays do: only right for a frame that is rendered again unchanged, a paused viewer)
         self.order_per_ray = bool(int(os.environ.get("RM_ORDER_PER_RAY", int(order_per_ray))))
 
+    def _apply(self, fn, *args, **kwargs):
+        """.to(device) / .half() / ...: buffers keyed on the old placement (dealing orders, cost maps, kernel choice,
+        converted camera buffers) are dropped rather than carried to a device they do not live on."""
+        self._order_state, self._choice_state, self._f32_cache = {}, {}, {}
+        return super()._apply(fn, *args, **kwargs)
+
     # cached conversions live outside the module's picklable state (copy.deepcopy / torch.save of a RenderLoop)
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -228,7 +234,7 @@ class RenderLoop(nn.Module):
         frames the GPU renders much later."""
         n, h, w, _ = rp.shape
         r0, r1 = rows if rows is not None else (0, h)
-        return self._choose_kernel_for((r0, r1, steps, torch.cuda.current_stream(rp.device).cuda_stream))
+        return self._choose_kernel_for((r0, r1, steps, rp.device.index, torch.cuda.current_stream(rp.device).cuda_stream))
 
     def _choose_kernel_for(self, key):
         """The state machine of _choose_kernel for one (band, step count, stream)."""
@@ -288,7 +294,7 @@ class RenderLoop(nn.Module):
         r0, r1 = rows if rows is not None else (0, h)
         dev = rp.device
         per_ray = regen and self.order_per_ray
-        key = (r0, r1, steps, self.tile8x8, regen, per_ray, torch.cuda.current_stream(dev).cuda_stream)
+        key = (r0, r1, steps, self.tile8x8, regen, per_ray, dev.index, torch.cuda.current_stream(dev).cuda_stream)
         st = self._order_state.get(key)
         if st is None:
             st = self._order_state[key] = self._new_order_state(rp, rows, regen)

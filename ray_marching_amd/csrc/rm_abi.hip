@@ -11,6 +11,7 @@
 #include RM_STATIC_CODE
 #endif
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -110,13 +111,24 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 bool env_set(const char* name) { const char* v = getenv(name); return v && *v; }
+// per-device caches (a process may render on several devices; HIP function attributes and the CU count are per
+// device): slot = the current device's ordinal, atomics because two host threads may race on the first use
+constexpr int RM_MAX_DEVICES = 64;
+int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RM_MAX_DEVICES) return -1;
+  return dev;
+}
 int cu_count() {
-  static int n = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-  }();
-  return n;
+  static std::atomic<int> cache[RM_MAX_DEVICES];
+  const int slot = current_device_slot();
+  int n = slot >= 0 ? cache[slot].load(std::memory_order_relaxed) : 0;
+  if (n > 0) return n;
+  int cus = 256;
+  if (slot >= 0) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, slot);
+  if (cus <= 0) cus = 256;
+  if (slot >= 0) cache[slot].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
 // frame kernel: 1280 blocks x 4 waves = 5 waves/SIMD measured best with the atomic tile queues
@@ -568,12 +580,13 @@ int rm_tile_order_from_cost(const int32_t* tile_cost, int64_t n_tiles, int32_t m
   if (n_tiles > RM_ORDER_ONE_BLOCK && !scratch)
     return fail(RM_E_BADARG, "rm_tile_order_from_cost: more than %d items need the scratch buffer", RM_ORDER_ONE_BLOCK);
   const size_t lds = (32 * 1024 + 64) * sizeof(int);      // 128 KiB of gfx950's 160 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set[RM_MAX_DEVICES];       // per device: function attributes do not carry over
+  const int slot = current_device_slot();
+  if (slot < 0 || !attr_set[slot].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rm::k_order_scatter),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(RM_E_LAUNCH, "hipFuncSetAttribute(k_order_scatter): %s", hipGetErrorString(e));
-    attr_set = true;
+    if (slot >= 0) attr_set[slot].store(true, std::memory_order_release);
   }
   // one block up to 4096 items (or without scratch), else ~4096 items per block: 1080p tiles 8 blocks, rays 256
   int blocks = 1;

@@ -189,3 +189,50 @@ def test_grey_shader_tiles_travel_as_one_channel():
             pay = tile_payload(rgb, mode)
             assert pay.shape == rgb.shape and torch.equal(expand_payload(pay), rgb)
     assert GREY_MODES == (0, 1, 2, 3, 5)
+
+
+# -- bench.py's own launcher (Missing 1): `python bench.py --gpus N` must produce N ranks by itself -----------
+def _bench(*argv, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("extra,scaling", [((), "weak"), (("--weak-mode", "tall"), "weak"),
+                                           (("--config", "5", "--exchange", "gather"), "strong")])
+def test_bench_self_launches_n_ranks(extra, scaling):
+    """A PLAIN `python bench.py --gpus 3` (no torchrun, WORLD_SIZE unset) starts 3 fresh ranks, which form a real
+    process group (gloo here), run the barriers / tile exchange / max-over-ranks timing of the real bench around a host
+    stand-in for the renderer, and rank 0's single JSON line comes back through the parent with n_gpus = the world
+    size the backend initialised."""
+    r, line = _bench("--gpus", "3", "--stub-render", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--repeats", "2", *extra)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1          # ONE line on stdout
+    assert line["stub"] is True and line["value"] is None                     # never mistaken for a measurement
+    assert line["n_gpus"] == 3 and line["requested_gpus"] == 3 and line["scaling"] == scaling
+    assert line["config"]["gathered_rows"] == {"weak": 3 * 54, "strong": 54}[scaling]
+    assert ("unequal" in line["config"]["work_per_rank"]) == bool(extra)
+
+
+def test_bench_self_launch_fails_loudly():
+    """Fewer GPUs than ranks -> non-zero exit before anything is started; a rank that dies -> non-zero exit, no line."""
+    if torch.cuda.device_count() < 2:
+        r, line = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert r.returncode != 0 and line is None and "GPU(s)" in r.stderr
+    r, line = _bench("--gpus", "2", "--stub-render", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--repeats", "1",
+                     "--stub-fail-rank", "1")
+    assert r.returncode != 0 and line is None, (r.returncode, r.stdout)
+    # started under a launcher with another world size than --gpus: refused
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-render"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -225,11 +225,12 @@ for z in (1.0, -3.0):
         assert torch.equal(a, b), (z, mode)
 print("PARKING-OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RM_HIPCC_EXTRA="-DRM_PARKING", RM_PARK="1", RM_SPECIALIZE="jit")
+    # the variant libraries go to a directory of their own (RM_LIB_DIR): the product library is never replaced
+    env = dict(os.environ, RM_HIPCC_EXTRA="-DRM_PARKING", RM_PARK="1", RM_SPECIALIZE="jit", RM_LIB_DIR=str(tmp_path / "lib"))
+    from ray_marching_amd import _build
+    before = open(_build.LIB_PATH + ".srchash").read()
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    # the child rebuilt ray_marching_amd/lib/librm_hip.so with the extra flag: put the default build back
-    import __graft_entry__ as entry
-    entry.build_library(force=True)
+    assert open(_build.LIB_PATH + ".srchash").read() == before and os.path.isfile(tmp_path / "lib" / "librm_hip.so")
     assert r.returncode == 0 and "PARKING-OK" in r.stdout, r.stderr[-2000:]
 
 

@@ -159,9 +159,12 @@ def test_captured_frame_with_regen_follows_the_camera():
             assert _same_bits(frame(q, t), tile(q, t, 4, 1, steps)), i
 
 
-def test_auto_mode_takes_the_faster_kernel():
-    """regen="auto" (the default) at 1080p: the pools inside the torus (0,0,1), the tile kernel in front of the scene
-    (0,0,-3): 404 vs 317 us and 214 vs 245 us per frame (profiles/regen_probe.py)."""
+def test_auto_mode_probes_both_kernels_and_never_changes_a_pixel():
+    """regen="auto" (the default) at 1080p: whichever kernel the timing heuristic is on, every frame has the tile
+    kernel's bits, and both kernels were really probed.  WHICH kernel wins on a shared box is printed, not asserted
+    (profiles/regen_probe.py: the pools inside the torus (0,0,1), the tile kernel in front of the scene (0,0,-3),
+    margins of 13-27 % that one noisy probe can flip); the decision logic itself is tested with injected timings in
+    tests/test_host_cpu.py::test_auto_kernel_choice_state_machine."""
     h, w, steps = 1080, 1920, 128
     tile = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False, adaptive_order=0)
     q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV)
@@ -177,7 +180,11 @@ def test_auto_mode_takes_the_faster_kernel():
                     assert _same_bits(got, want), (z, i)
                 torch.cuda.synchronize()
         (st,) = auto._choice_state.values()
-        assert st["regen"] is want_regen, (z, st["log"])
+        assert st["log"], "no pair of probes completed in 160 waited-for frames"
+        for n_frame, was_regen, ms_other, ms_used in st["log"]:
+            assert 0.0 < ms_other < 1e3 and 0.0 < ms_used < 1e3, st["log"]
+        print(f"regen=auto at z={z:+g}: ends on {'the pool kernels' if st['regen'] else 'the tile kernel'} "
+              f"(expected on a quiet box: {'pools' if want_regen else 'tile'}); probes (frame, pools in use, ms other, ms used): {st['log'][-4:]}")
 
 
 @pytest.mark.parametrize("seed", range(8))
