@@ -195,6 +195,53 @@ def config3_probe(dev):
     return out
 
 
+def reference_shape_probe(dev):
+    """The reference's own run shape (main.py:20-26, 46, 65-88): make_test_scene2, 1440x900, 32 march steps, the
+    module cast with .to(float16), pose (0,0,1), one frame = render_loop(...) followed by the display contract
+    F.pad(images.mean(0).float(), [0,1], 1.0) -> [H,W,4] fp32 (window.draw's input, torchwindow/window.py:146-174).
+    `fps_waited` waits for every frame like main.py's loop does (window.draw copies on the legacy stream);
+    `ms_per_frame` is the same loop without the wait.  Modes: lambertian (main.py's first mode) and normal."""
+    import torch.nn.functional as F
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    h, w, steps = 900, 1440, 32
+    loop = RenderLoop(make_test_scene2().to(dev, torch.float16), num_cameras=1, px_width=w, px_height=h, focal_length=PX * h,
+                      sensor_width=PX * w, sensor_height=PX * h, normals_eps=EPS).to(dev, torch.float16)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev, dtype=torch.float16)
+    t = torch.tensor([[0.0, 0.0, 1.0]], device=dev, dtype=torch.float16)
+    out = {"shape": "make_test_scene2 1440x900, 32 steps, float16 module, pose (0,0,1) (main.py:20-26,46)", "modes": {}}
+
+    def frame(mode):
+        images = loop(q, t, mode, 1, steps)
+        return F.pad(images.mean(dim=0).float(), pad=[0, 1], value=1.0)
+
+    with torch.no_grad():
+        for mode, name in ((0, "lambertian"), (4, "normal")):
+            for _ in range(20):
+                frame(mode)
+            torch.cuda.synchronize()
+            n = 200
+            t0 = time.perf_counter()
+            for _ in range(n):
+                frame(mode)
+            torch.cuda.synchronize()
+            free = (time.perf_counter() - t0) / n * 1e3
+            t0 = time.perf_counter()
+            for _ in range(n):
+                frame(mode)
+                torch.cuda.synchronize()
+            waited = (time.perf_counter() - t0) / n * 1e3
+            t0 = time.perf_counter()
+            for _ in range(n):
+                loop(q, t, mode, 1, steps)
+            torch.cuda.synchronize()
+            render = (time.perf_counter() - t0) / n * 1e3
+            out["modes"][name] = {"ms_per_frame": free, "fps": 1e3 / free, "ms_per_frame_waited": waited,
+                                  "fps_waited": 1e3 / waited, "render_only_ms": render,
+                                  "Mrays_per_s": h * w / free / 1e3}
+    return out
+
+
 def backward_probe(dev):
     """Secondary metric 'fwd+bwd ms/frame' (BASELINE config 4 shape): closed make_test_scene,
     512x512, 64 steps, Lambertian MSE loss, gradients of all 40 scene parameters."""
@@ -246,9 +293,10 @@ def backward_probe(dev):
         walls.append((time.perf_counter() - t0) / n * 1e3)
     wall = sorted(walls)[len(walls) // 2]
     rays, S = h * w, 64
-    # algorithmic HBM bytes of one step: forward 24 in + 12 out + 12 p_final + the trajectory written
-    # (12 S); backward reads the trajectory, p_final, the image gradient and the ray directions (12 (S + 3))
-    step_bytes = rays * ((24 + 12 + 12 + 12 * S) + 12 * (S + 3))
+    n_bytes = step_bytes(rays, S)
+    traffic, why = backward_traffic_record(h)
+    if why:
+        log(f"fwd_bwd.roofline.traffic: {why}")
     out = {"config": "closed make_test_scene 512x512x64, lambertian MSE, 40 parameters",
            "fwd_bwd_ms": wall,
            "note": "fwd_bwd_ms = wall time per step of a 100-step eager loop with no synchronisation inside; *_sync_ms = "
@@ -259,9 +307,9 @@ def backward_probe(dev):
            "fwd_bwd_ms_runs": walls,
            "fwd_sync_ms": sync_fwd, "bwd_sync_ms": sync_bwd, "fwd_bwd_sync_ms": sync_fwd + sync_bwd,
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_step": step_bytes,
-                        "achieved": step_bytes / (wall * 1e-3) / 1e9, "frac": step_bytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None,
+                        "algorithmic_bytes_per_step": n_bytes,
+                        "achieved": n_bytes / (wall * 1e-3) / 1e9, "frac": n_bytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic,
                         "binding": "neither roof: at this frame size the step is bound by VALU issue at 2-4 waves per SIMD "
                                    "and by the longest wave tile of each launch (DESIGN.md 7)"}}
     # the same forward + backward captured once in a HIP graph (torch.cuda.graph) and replayed: the eager
@@ -274,9 +322,14 @@ def backward_probe(dev):
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-leg"], capture_output=True,
-                               text=True, timeout=180)
+                               text=True, timeout=300)
             if r.returncode == 0:
-                out["graph_fwd_bwd_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["graph_fwd_bwd_ms"]
+                leg = json.loads(r.stdout.strip().splitlines()[-1])
+                out["graph_fwd_bwd_ms"] = leg["graph_fwd_bwd_ms"]
+                # throughput mode: the same step at 1024^2 and 2048^2 (512^2 is 4 wave tiles per SIMD: a latency floor)
+                out["size_sweep"] = leg["sweep"]
+                g = n_bytes / (leg["graph_fwd_bwd_ms"] * 1e-3) / 1e9
+                out["roofline"]["graph"] = {"achieved": g, "frac": g / HBM_PEAK_GBS}
                 # the replay is the GPU work of a step; an eager loop well above it is waiting for the host (Python,
                 # autograd's 40 AccumulateGrad nodes, ~20 launches), not for the kernels
                 out["eager_loop_is_host_bound"] = bool(wall > 1.1 * out["graph_fwd_bwd_ms"])
@@ -287,35 +340,70 @@ def backward_probe(dev):
     return out
 
 
+def step_bytes(rays, S=64):
+    """Algorithmic HBM bytes of one config-4 training step: forward 24 in + 12 out + 12 p_final + the
+    trajectory written (12 S); backward reads the trajectory, p_final, the image gradient and the ray directions
+    (12 (S + 3))."""
+    return rays * ((24 + 12 + 12 + 12 * S) + 12 * (S + 3))
+
+
 def graph_leg():
-    """Child process of backward_probe: forward + backward of the config-4 shape captured with
-    torch.cuda.graph and replayed; prints {"graph_fwd_bwd_ms": ...}."""
+    """Child process of backward_probe: forward + backward of the config-4 scene captured with torch.cuda.graph and
+    replayed, at 512^2 (BASELINE configs[3]) and, as a size sweep, at 1024^2 and 2048^2 -- what the kernels reach
+    once the GPU is full instead of 4 wave tiles per SIMD.  Prints {"graph_fwd_bwd_ms": ..., "sweep": {...}}."""
     from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.graphs import capture_step
     from ray_marching_amd.scene.scene_registry import make_closed_test_scene
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    h = w = 512
-    scene = make_closed_test_scene()
-    loop = RenderLoop(scene, num_cameras=1, px_width=w, px_height=h, focal_length=PX * h, sensor_width=PX * w,
-                      sensor_height=PX * h, normals_eps=EPS).to(dev)
     q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
     t = torch.tensor([[0.0, 0.0, -1.0]], device=dev)
-    target = torch.rand(1, h, w, 1, device=dev)
-    params = list(scene.parameters())
+    out = {"sweep": {}}
+    for size in (512, 1024, 2048):
+        h = w = size
+        scene = make_closed_test_scene()
+        loop = RenderLoop(scene, num_cameras=1, px_width=w, px_height=h, focal_length=PX * h, sensor_width=PX * w,
+                          sensor_height=PX * h, normals_eps=EPS).to(dev)
+        target = torch.rand(1, h, w, 1, device=dev)
+        params = list(scene.parameters())
 
-    def step():
-        (loop(q, t, 0, 1, 64)[..., :1] - target).pow(2).mean().backward()
+        def step():
+            (loop(q, t, 0, 1, 64)[..., :1] - target).pow(2).mean().backward()
 
-    from ray_marching_amd.graphs import capture_step
-    graph, _, _ = capture_step(step, params, warmup=3)      # warm-up and capture on ONE stream (graphs.py)
-    graph.replay()
-    torch.cuda.synchronize()
-    n = 50
-    t0 = time.perf_counter()
-    for _ in range(n):
+        graph, _, _ = capture_step(step, params, warmup=3)      # warm-up and capture on ONE stream (graphs.py)
         graph.replay()
-    torch.cuda.synchronize()
-    print(json.dumps({"graph_fwd_bwd_ms": (time.perf_counter() - t0) / n * 1e3}), flush=True)
+        torch.cuda.synchronize()
+        n = 50 if size == 512 else 12
+        runs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                graph.replay()
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0) / n * 1e3)
+        ms = sorted(runs)[1]
+        gbs = step_bytes(h * w) / (ms * 1e-3) / 1e9
+        out["sweep"][f"{size}x{size}"] = {"graph_fwd_bwd_ms": ms, "achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                            "Mrays_per_s": h * w / ms / 1e3}
+        if size == 512:
+            out["graph_fwd_bwd_ms"] = ms
+        del graph, loop, scene, target, params
+        torch.cuda.empty_cache()
+    print(json.dumps(out), flush=True)
+
+
+def backward_traffic_record(size):
+    """HBM bytes of one config-4 training step from the PMC passes (profiles/collect_r03.sh ->
+    profiles/traffic_bwd.json) -- only if measured on THESE kernel sources."""
+    prof = os.path.join(ROOT, "profiles", "traffic_bwd.json")
+    if not os.path.isfile(prof):
+        return None, "profiles/traffic_bwd.json missing"
+    with open(prof) as f:
+        pmc = json.load(f)
+    from ray_marching_amd import _build
+    if pmc.get("sources_hash") != _build.sources_hash():
+        return None, "profiles/traffic_bwd.json was measured on other kernel sources (hash mismatch): traffic = null"
+    return pmc.get(f"hbm_bytes_per_step_{size}"), None
 
 
 def traffic_record(specialised, args):
@@ -696,6 +784,7 @@ def main():
             out["pipelined"] = pipelined_probe(loop, q, t, rows, dev, rays_per_frame)
             if not args.skip_config3:
                 out["config3"] = config3_probe(dev)
+            out["reference_shape"] = reference_shape_probe(dev)
         if not args.skip_backward and not config5:
             log("backward probe (config 4 shape) ...")
             out["fwd_bwd"] = backward_probe(dev)

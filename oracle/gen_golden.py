@@ -263,9 +263,14 @@ def gen_f9(ref):
     h, w, steps = 54, 96, 128
     q = torch.tensor([[1.0, 0.0, 0.0, 0.0]]); t = torch.tensor([[0.0, 0.0, -4.5]])
     images, aux = frame(ref, O.scene_many(32), h, w, q, t, steps, [0, 4], degree=1)
+    # the reference's own float64 render of the same frame (same fp32 parameter / camera values, cast like .to(float64)
+    # casts them): |fp32 - fp64| per pixel is the reference's own conditioning there, which the GPU test uses to say
+    # WHICH pixels may differ by more than 1e-5 (grazing rays at blend creases)
+    images64, aux64 = frame(ref, O.scene_many(32), h, w, q, t, steps, [0, 4], degree=1, dtype=torch.float64)
     save("f9_many32_54x96_s128.npz", hw=np.array([h, w]), steps=np.array(steps), q=npy(q), t=npy(t),
          eps=np.array(EPS), p=npy(aux["p"]), n=npy(aux["n"]), dist=npy(aux["dist"]),
-         mode0=npy(images[0][..., :1]), mode4=npy(images[4]))
+         mode0=npy(images[0][..., :1]), mode4=npy(images[4]),
+         p_f64=npy(aux64["p"]), mode0_f64=npy(images64[0][..., :1]), mode4_f64=npy(images64[4]))
 
 
 def main():

@@ -55,6 +55,8 @@ def run(name, spec):
         else:
             flags.append(tok)
     env["RM_HIPCC_EXTRA"] = " ".join(flags)
+    # every variant builds into a directory of its own: the product library is never replaced (ray_marching_amd/_build.py)
+    env["RM_LIB_DIR"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rm_ab_" + "".join(c if c.isalnum() else "_" for c in name))
     t0 = time.time()
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     res = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
