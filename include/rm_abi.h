@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 10
+#define RM_ABI_VERSION 11
 
 enum {
   RM_DTYPE_F32 = 0,
@@ -66,8 +66,10 @@ enum {
   RM_OP_UNION_BEGIN = 9,   /*                               transformations.py:90-94 */
   RM_OP_FOLD_MIN = 10,     /* aux0 = tape slot; aux1 = distance back to its CULL_MIN (0 = none) */
   RM_OP_UNION_END = 11,    /* aux0 = first tape slot, aux1 = child count */
-  RM_OP_SMOOTH_BEGIN = 12, /*                               transformations.py:67-71 */
-  RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot */
+  RM_OP_SMOOTH_BEGIN = 12, /* P: blend_k (read only when aux0 != 0); aux0 = derived offset of the children's bound table, 8 floats per
+                              child in slot order (0 = no culling inside this smooth union), aux1 = first tape slot << 8 | child count
+                              (<= 64 children, slots < 64)    transformations.py:67-71 */
+  RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot; aux1 = distance back to its CULL_LSE (0 = none) */
   RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count; slot aux0+aux1 holds the logsumexp */
   RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
   RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
@@ -75,7 +77,12 @@ enum {
                               {cx,cy,cz,K,slope} written by the kernels at staging time; aux1 = (n << 8) | slot, n = instructions up to and including the
                               child's FOLD_MIN (whose aux1 = n).  Skips the child when it cannot lower the
                               running minimum for any ray of the wave (exact) */
-  RM_OP__COUNT = 18
+  RM_OP_CULL_LSE = 18,     /* before a child of an SDFSmoothUnion whose SMOOTH_BEGIN carries a bound table: `param offset` field =
+                              derived offset of this child's table entry {cx,cy,cz,slope_lb,K_lb,slope_ub,K_ub,0} (written by the
+                              kernels at staging time), aux0 = the child's tape slot, aux1 = n = instructions up to and including
+                              the child's FOLD_LSE (whose aux1 = n).  Skips the child when its term of the logsumexp is exactly
+                              +0.0f for every ray of the wave: k (d_i - d_min) > 104 (exact) */
+  RM_OP__COUNT = 19
 };
 
 /* Where one float of the parameter block lives: element `elem` of a device array of `dtype` (F32 or F16).
@@ -97,6 +104,9 @@ typedef struct RmScene {
   int32_t n_derived;       /* derived constants appended in LDS after the raw block */
   int32_t stack_floats;    /* per-ray evaluation stack depth (floats) */
   int32_t n_slots;         /* per-ray tape slots (fold / onion inputs) */
+  int32_t n_grad_derived;  /* leading floats of the derived block that carry gradients (capsule constants); the rest
+                              (cull bounds, bound tables) has none, so the backward kernels keep
+                              n_params + n_grad_derived accumulators per ray */
 } RmScene;
 
 /* PinholeCamera buffers (rendering/ray_marching.py:26-50). */

@@ -14,7 +14,7 @@ import os
 # ROCm-capable device is detected" (seen on the GPU box with build() followed by smoke() in one process).
 import torch  # noqa: F401,E402
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _HERE = os.path.dirname(os.path.abspath(__file__))
 from ._build import LIB_PATH  # noqa: E402  (ray_marching_amd/lib/librm_hip.so, or under RM_LIB_DIR)
 
@@ -25,6 +25,7 @@ OP_UNION_BEGIN, OP_FOLD_MIN, OP_UNION_END = 9, 10, 11
 OP_SMOOTH_BEGIN, OP_FOLD_LSE, OP_SMOOTH_END = 12, 13, 14
 OP_ROUND, OP_ONION = 15, 16
 OP_CULL_MIN = 17
+OP_CULL_LSE = 18
 
 FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES, FLAG_REGEN, FLAG_ORDER_PER_RAY = 1, 2, 4, 8, 16
 ORDER_ONE_BLOCK, ORDER_SCRATCH_INTS = 131072, 8192
@@ -43,7 +44,7 @@ MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian
 class RmScene(C.Structure):
     _fields_ = [("program", C.c_void_p), ("params", C.c_void_p), ("param_refs", C.c_void_p), ("n_instr", C.c_int32),
                 ("n_params", C.c_int32), ("n_derived", C.c_int32), ("stack_floats", C.c_int32),
-                ("n_slots", C.c_int32)]
+                ("n_slots", C.c_int32), ("n_grad_derived", C.c_int32)]
 
 
 class RmCamera(C.Structure):

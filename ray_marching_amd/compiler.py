@@ -33,6 +33,9 @@ _STACK_UNION, _STACK_SMOOTH, _STACK_AFFINE = 2, 2, 6
 # (~9 instructions when it fails) is worth emitting in front of it
 _LEAF_COST = {"sphere": 13, "box": 22, "plane": 1, "line": 30, "disk": 20, "torus": 24}
 _CULL_MIN_CHILD_COST = 40
+# smooth unions with at least this many children get the exact logsumexp culling (RM_OP_CULL_LSE; the wave-wide test
+# costs ~45 instructions per evaluation whatever the number of children)
+_CULL_LSE_MIN_CHILDREN = 8
 
 
 def _cost(node) -> int:
@@ -72,6 +75,7 @@ class CompiledScene:
     leaf_offsets: list
     n_params: int
     n_derived: int
+    n_grad_derived: int                 # leading derived floats that carry gradients (capsule constants)
     stack_floats: int
     n_slots: int
     signature: tuple                    # topology key (ops + offsets), parameters excluded
@@ -178,7 +182,7 @@ class CompiledScene:
         s = _abi.RmScene(program=prog.data_ptr(), params=None if params is None else params.data_ptr(),
                          param_refs=None if (params is not None or table is None) else table.data_ptr(),
                          n_instr=self.n_instr, n_params=self.n_params, n_derived=self.n_derived,
-                         stack_floats=self.stack_floats, n_slots=self.n_slots)
+                         stack_floats=self.stack_floats, n_slots=self.n_slots, n_grad_derived=self.n_grad_derived)
         return s, (prog, params, table)
 
 
@@ -188,12 +192,19 @@ class _Emitter:
         self.code = []
         self.n_slots = 0
         self.n_derived = 0
+        self.n_grad_derived = 0        # capsule constants: reserved at the front of the derived block (they carry gradients)
+        self.next_line = 0
         self.depth = 0
         self.max_depth = 0
         self.cull = os.environ.get("RM_CULL", "1") != "0"    # RM_CULL=0: no CULL_MIN instructions (A/B tests)
         # RM_CULL_MIN_COST=0: a cull test in front of every boundable child, however cheap (stress tests)
         self.cull_min_cost = int(os.environ.get("RM_CULL_MIN_COST", _CULL_MIN_CHILD_COST))
         self.cull_reorder = os.environ.get("RM_CULL_REORDER", "1") != "0"
+        # RM_CULL_LSE=1: exact culling inside smooth unions (opt-in: it pays when the children are spread over much more
+        # than 104 / blend_k; in the config-5 scene 2.8 % of the child evaluations qualify, profiles/r03_lse_cull_rate.txt,
+        # and the wave-wide test costs more than they save); RM_CULL_LSE_MIN: children from which on it is emitted
+        self.cull_lse = os.environ.get("RM_CULL_LSE", "0") == "1"
+        self.cull_lse_min = int(os.environ.get("RM_CULL_LSE_MIN", _CULL_LSE_MIN_CHILDREN))
 
     def off(self, *params):
         """Offset of the first parameter; the rest must follow contiguously."""
@@ -227,8 +238,8 @@ def _emit(node, em: _Emitter, n_params: int):
     elif kind == "plane":
         em.ins(A.OP_PLANE)
     elif kind == "line":
-        derived = n_params + em.n_derived
-        em.n_derived += 6
+        derived = n_params + em.next_line       # one of the slots reserved at the front of the derived block
+        em.next_line += 6
         em.ins(A.OP_LINE, em.off(node.start, node.end, node.radius), derived)
     elif kind == "disk":
         em.ins(A.OP_DISK, em.off(node.radius))
@@ -252,7 +263,19 @@ def _emit(node, em: _Emitter, n_params: int):
         smooth = kind == "smooth_union"
         em.n_slots += len(kids) + (1 if smooth else 0)     # smooth union: one more slot for the logsumexp value
         koff = em.off(node.blend_k) if smooth else 0
-        em.ins(A.OP_SMOOTH_BEGIN if smooth else A.OP_UNION_BEGIN)
+        # Exact culling inside a smooth union: a child whose term of the logsumexp is exactly +0.0f for every ray of the
+        # wave (k (d_i - d_min) > 104) is skipped -- value, argmax and gradients unchanged (rm_device.h: lse_cull_mask).
+        # The test runs once per evaluation, one child per lane, from a table of bounds (8 floats per child, 16-byte
+        # aligned, filled in on the device); the skip bits live at the children's tape slots, hence slots < 64.
+        lse_table = 0
+        if smooth and em.cull and em.cull_lse and em.cull_lse_min <= len(kids) <= 64 and base + len(kids) <= 64:
+            em.n_derived += (-(n_params + em.n_derived)) % 4
+            lse_table = n_params + em.n_derived
+            em.n_derived += 8 * len(kids)
+        if smooth:
+            em.ins(A.OP_SMOOTH_BEGIN, koff if lse_table else 0, lse_table, ((base << 8) | len(kids)) if lse_table else 0)
+        else:
+            em.ins(A.OP_UNION_BEGIN)
         em.push(_STACK_SMOOTH if smooth else _STACK_UNION)
         # Exact culling of min-union children.  min() does not care about the order its operands arrive in,
         # and the reverse pass finds the winner from the tape slots, which stay in the reference's child
@@ -271,11 +294,19 @@ def _emit(node, em: _Emitter, n_params: int):
                 cull_at = len(em.code)
                 em.ins(A.OP_CULL_MIN, 0, n_params + em.n_derived, 0)      # aux1 patched below
                 em.n_derived += 5      # {cx, cy, cz, K, slope}, filled in on the device
+            lse_at = None
+            if lse_table:
+                lse_at = len(em.code)
+                em.ins(A.OP_CULL_LSE, lse_table + 8 * i, base + i, 0)           # aux1 patched below
             _emit(child, em, n_params)
             if cull_at is not None:
                 skip = len(em.code) - cull_at
                 em.code[cull_at] = (A.OP_CULL_MIN, 0, em.code[cull_at][2], (skip << 8) | (base + i))
                 em.ins(A.OP_FOLD_MIN, 0, base + i, skip)
+            elif lse_at is not None:
+                skip = len(em.code) - lse_at
+                em.code[lse_at] = (A.OP_CULL_LSE, lse_table + 8 * i, base + i, skip)
+                em.ins(A.OP_FOLD_LSE, koff, base + i, skip)
             else:
                 em.ins(A.OP_FOLD_LSE if smooth else A.OP_FOLD_MIN, koff, base + i)
         em.pop(_STACK_SMOOTH if smooth else _STACK_UNION)
@@ -307,14 +338,18 @@ def compile_scene(module: nn.Module) -> CompiledScene:
         cursor += p.numel()
     n_params = cursor
     em = _Emitter(table)
+    # derived block = [capsule constants of every SDFLine (gradients flow through them) | cull bounds, bound tables]
+    em.n_grad_derived = em.n_derived = 6 * sum(1 for m in module.modules() if getattr(m, "_rm_kind", None) == "line")
     _emit(module, em, n_params)
+    if em.next_line != em.n_grad_derived:
+        raise ValueError("an SDF node instance appears more than once in the scene tree (shared sub-modules are not supported)")
     program = np.asarray(em.code, dtype=np.int32).reshape(-1, 4)
     rc = _abi.lib.rm_validate_program(program.ctypes.data, program.shape[0], n_params, em.n_derived,
                                       em.max_depth, em.n_slots)
     _abi.check(rc, "rm_validate_program")
-    signature = (tuple(map(tuple, program.tolist())), n_params, em.n_derived, em.max_depth, em.n_slots)
+    signature = (tuple(map(tuple, program.tolist())), n_params, em.n_derived, em.max_depth, em.n_slots, em.n_grad_derived)
     return CompiledScene(program=program, leaves=leaves, leaf_names=names, leaf_offsets=offsets,
-                         n_params=n_params, n_derived=em.n_derived, stack_floats=em.max_depth,
+                         n_params=n_params, n_derived=em.n_derived, n_grad_derived=em.n_grad_derived, stack_floats=em.max_depth,
                          n_slots=em.n_slots, signature=signature)
 
 

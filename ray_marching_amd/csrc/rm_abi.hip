@@ -42,7 +42,7 @@ int check_scene(const RmScene* sc) {
   if (!sc || !sc->program || (!sc->params && !sc->param_refs && sc->n_params > 0))
     return fail(RM_E_BADARG, "scene: null program/params");
   if (sc->n_instr <= 0 || sc->n_instr > 4096 || sc->n_params < 0 || sc->n_derived < 0 ||
-      sc->stack_floats < 0 || sc->n_slots < 0)
+      sc->stack_floats < 0 || sc->n_slots < 0 || sc->n_grad_derived < 0 || sc->n_grad_derived > sc->n_derived)
     return fail(RM_E_BADARG, "scene: bad sizes (n_instr=%d n_params=%d)", sc->n_instr, sc->n_params);
   return check_static(sc);
 }
@@ -63,11 +63,12 @@ using GB = rm::StaticCfg<RmStaticCode, RM_BWD_REG_PARAMS>;   // backward kernels
 // static path: parameter block + (backward) one accumulator row per wave for the block reduction
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
-  return 4 * (pb + (backward ? (size_t)(block >> 6) * (sc.n_params + sc.n_derived) : 0) + 4);
+  return 4 * (pb + (backward ? (size_t)(block >> 6) * (sc.n_params + sc.n_grad_derived) : 0) + 4 + (size_t)G::kTapeFloats);
 }
 int check_static(const RmScene* sc) {
   if (sc->n_instr != RmStaticCode::n || sc->n_params != RmStaticCode::n_params ||
-      sc->n_derived != RmStaticCode::n_derived || sc->n_slots != RmStaticCode::n_slots)
+      sc->n_derived != RmStaticCode::n_derived || sc->n_slots != RmStaticCode::n_slots ||
+      sc->n_grad_derived != RmStaticCode::n_grad_derived)
     return fail(RM_E_PROGRAM, "scene does not match the program this library was specialised for");
   return RM_OK;
 }
@@ -78,7 +79,7 @@ int check_static(const RmScene*) { return RM_OK; }
 // LDS bytes of the generic path for a block of `block` threads.
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
-  size_t per_thread = (size_t)sc.stack_floats + sc.n_slots + (backward ? sc.n_params + sc.n_derived : 0);
+  size_t per_thread = (size_t)sc.stack_floats + sc.n_slots + (backward ? sc.n_params + sc.n_grad_derived : 0);
   return 4 * (pb + 4 * (size_t)sc.n_instr + per_thread * (block + 1));
 }
 #endif
@@ -144,7 +145,7 @@ int launched(const char* what) {
 // partials holds kPartialRows rows of per-block sums followed by one row of totals
 int reduce_partials(const RmScene& sc, float* partials, int nblocks, float* grad_params, hipStream_t s) {
   if (!grad_params) return RM_OK;
-  const int n_acc = sc.n_params + sc.n_derived;
+  const int n_acc = sc.n_params + sc.n_grad_derived;
   if (n_acc == 0) return RM_OK;
   float* sums = partials + (size_t)kPartialRows * n_acc;
   rm::k_reduce_partials<<<n_acc, 256, 0, s>>>(partials, nblocks, n_acc, sums);
@@ -165,7 +166,7 @@ const char* rm_last_error(void) { return g_err; }
 int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
   if (!scene) return 0;
   (void)n;
-  return (int64_t)(kPartialRows + 1) * (scene->n_params + scene->n_derived);
+  return (int64_t)(kPartialRows + 1) * (scene->n_params + scene->n_grad_derived);
 }
 
 int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps) {
@@ -564,7 +565,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     rm::k_bwd_hard_a<<<(int)((hard_capacity + 63) / 64), 64, 0, (hipStream_t)stream>>>(a);   // one wave per block: more CUs busy
     if (int e = launched("k_bwd_hard_a")) return e;
     rm::RenderArgs b = a;
-    b.partials = partials + (size_t)rows * (scene->n_params + scene->n_derived);     // its rows follow k_render_bwd's
+    b.partials = partials + (size_t)rows * (scene->n_params + scene->n_grad_derived);     // its rows follow k_render_bwd's
     rm::k_bwd_hard_b<GB><<<kHardBlocksB, LB.block, LB.lds, (hipStream_t)stream>>>(b);
     if (int e = launched("k_bwd_hard_b")) return e;
     rows += kHardBlocksB;
@@ -627,7 +628,7 @@ int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, vo
 int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_params, int32_t n_derived,
                         int32_t stack_floats, int32_t n_slots) {
   if (!host_program || n_instr <= 0) return fail(RM_E_PROGRAM, "empty program");
-  static const int psize[RM_OP__COUNT] = {0, 1, 3, 0, 7, 1, 2, 7, 7, 0, 0, 0, 0, 1, 1, 1, 1, 0};
+  static const int psize[RM_OP__COUNT] = {0, 1, 3, 0, 7, 1, 2, 7, 7, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0};
   int depth_f = 0, depth_b = 0, max_f = 0, max_b = 0, values = 0;
   for (int i = 0; i < n_instr; ++i) {
     const int32_t* w = host_program + 4 * i;
@@ -645,7 +646,16 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_AFFINE_PUSH: depth_f += 3; depth_b += 6; break;
       case RM_OP_AFFINE_POP: depth_f -= 3; depth_b -= 6; break;
       case RM_OP_UNION_BEGIN: depth_f += 1; depth_b += 2; break;
-      case RM_OP_SMOOTH_BEGIN: depth_b += 2; break;
+      case RM_OP_SMOOTH_BEGIN:
+        depth_b += 2;
+        if (a0 != 0) {     // bound table of an exactly culled smooth union
+          const int base = a1 >> 8, n = a1 & 255;
+          if (off < 0 || off >= n_params) return fail(RM_E_PROGRAM, "instr %d: SMOOTH_BEGIN blend_k out of range", i);
+          if (n < 1 || n > 64 || base < 0 || base + n > 64 || base + n > n_slots || a0 < n_params || (a0 & 3) ||
+              a0 + 8 * n > n_params + n_derived)
+            return fail(RM_E_PROGRAM, "instr %d: SMOOTH_BEGIN bound table out of range", i);
+        }
+        break;
       case RM_OP_UNION_END: case RM_OP_SMOOTH_END:
         if (a1 <= 0 || a0 < 0 || a0 + a1 + (op == RM_OP_SMOOTH_END ? 1 : 0) > n_slots)
           return fail(RM_E_PROGRAM, "instr %d: slots out of range", i);
@@ -656,11 +666,22 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_FOLD_MIN: case RM_OP_FOLD_LSE: case RM_OP_ONION:
         if (a0 < 0 || a0 >= n_slots) return fail(RM_E_PROGRAM, "instr %d: slot out of range", i);
         if (op != RM_OP_ONION) values--;
+        if (op == RM_OP_FOLD_LSE && a1 != 0) {
+          const int c = i - a1;
+          if (a1 < 0 || c < 0 || host_program[4 * c] != RM_OP_CULL_LSE || host_program[4 * c + 2] != a0 || host_program[4 * c + 3] != a1)
+            return fail(RM_E_PROGRAM, "instr %d: FOLD_LSE does not point back at its CULL_LSE", i);
+        }
         if (op == RM_OP_FOLD_MIN && a1 != 0) {
           const int c = i - a1;
           if (a1 < 0 || c < 0 || host_program[4 * c] != RM_OP_CULL_MIN || host_program[4 * c + 3] != ((a1 << 8) | a0))
             return fail(RM_E_PROGRAM, "instr %d: FOLD_MIN does not point back at its CULL_MIN", i);
         }
+        break;
+      case RM_OP_CULL_LSE:
+        if (off < n_params || (off & 3) || off + 8 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: bound entry out of range", i);
+        if (a1 < 2 || i + a1 >= n_instr || a0 < 0 || a0 >= 64 || a0 >= n_slots || host_program[4 * (i + a1)] != RM_OP_FOLD_LSE ||
+            host_program[4 * (i + a1) + 2] != a0 || host_program[4 * (i + a1) + 3] != a1)
+          return fail(RM_E_PROGRAM, "instr %d: CULL_LSE does not match its FOLD_LSE", i);
         break;
       case RM_OP_CULL_MIN: {
         const int skip = a1 >> 8, slot = a1 & 255;

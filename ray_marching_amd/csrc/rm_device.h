@@ -125,6 +125,44 @@ RM_DEV float aten_inner_sum(int n, F e) {
   }
   return fin;
 }
+// The same association with the element count known at compile time and every loop unrolled, so that e(i) is called
+// with constant indices: a tape kept in registers (RegStore) must never be indexed dynamically, or the whole store
+// goes to scratch memory (measured on the 32-child smooth union of config 5: 1732 B of scratch per lane, 16.7 GB of
+// HBM writes per 7680x540 band).
+template <int N, class F>
+RM_DEV float aten_inner_sum_n(F e) {
+  if constexpr (N < 4) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s = s + e(i);
+    return s;
+  } else if constexpr (N < 8) {
+    float p0 = e(0), p1 = e(1), p2 = e(2), p3 = e(3);
+#pragma unroll
+    for (int i = 4; i < N; ++i) p0 = p0 + e(i);
+    return ((p0 + p1) + p2) + p3;
+  } else {
+    constexpr int nv = N >> 3, k = nv >> 2;
+    float fin = 0.0f;
+#pragma unroll
+    for (int i = nv * 8; i < N; ++i) fin = fin + e(i);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < k; ++i) {
+        p0 = p0 + e((4 * i) * 8 + l);
+        p1 = p1 + e((4 * i + 1) * 8 + l);
+        p2 = p2 + e((4 * i + 2) * 8 + l);
+        p3 = p3 + e((4 * i + 3) * 8 + l);
+      }
+#pragma unroll
+      for (int i = 4 * k; i < nv; ++i) p0 = p0 + e(i * 8 + l);
+      fin = fin + (((p0 + p1) + p2) + p3);
+    }
+    return fin;
+  }
+}
 // ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
 RM_DEV float norm3(V3 a) { return rm_sqrt(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
 RM_DEV float norm2(float a, float b) { return rm_sqrt(__builtin_fmaf(b, b, a * a)); }
@@ -175,6 +213,29 @@ struct RegStore {
   RM_DEV void add(int i, float v) { r[i] += v; }
 };
 
+// Registers for the evaluation stack and the gradient accumulators, LDS columns for the TAPE: a large smooth union
+// keeps one tape slot per child alive across the evaluation of all its children (32 + 1 for the config-5 scene); as
+// registers they cost the frame kernel its occupancy (256 VGPRs + 124 AGPRs, 1 wave per SIMD, when the compiler is
+// left alone), as scratch memory 16.7 GB of HBM writes per 8K band.  Column stride is a compile-time constant, so
+// every access is one ds_read / ds_write with an immediate offset (34 slots x 257 x 4 B < the 64 KiB offset field).
+constexpr int kLdsTapeStride = 257;          // blocks of up to 256 threads
+template <int NStack, int NSlots, int NTotal>
+struct HybridStore {
+  float r[(NTotal - NSlots) > 0 ? (NTotal - NSlots) : 1];
+  float* base;   // per thread: column of this thread in the block's tape area
+  RM_DEV float ld(int i) const {
+    if (i < NStack) return r[i];
+    if (i < NStack + NSlots) return base[(i - NStack) * kLdsTapeStride];
+    return r[i - NSlots];
+  }
+  RM_DEV void st(int i, float v) {
+    if (i < NStack) r[i] = v;
+    else if (i < NStack + NSlots) base[(i - NStack) * kLdsTapeStride] = v;
+    else r[i - NSlots] = v;
+  }
+  RM_DEV void add(int i, float v) { st(i, ld(i) + v); }
+};
+
 // Parameter block views.  LdsParams reads the staged block where it is needed (generic
 // interpreter: the offset is only known at run time).  RegParams copies the block out of LDS
 // once per thread into wave-uniform registers (readfirstlane -> SGPRs) so a specialised march
@@ -216,7 +277,8 @@ struct Fwd {
   int tape0;   // index of tape slot 0 inside the store
   Store* st;
   bool record; // record every fold/onion input (needed by the reverse sweep)
-  unsigned long long culled;  // wave-uniform: bit s set = the union child folding into tape slot s was skipped
+  const float* lds;  // the staged parameter block in LDS (raw + derived), whatever view `P` the handlers read through
+  unsigned long long culled;  // wave-uniform: bit s set = the union / smooth-union child folding into tape slot s was skipped
   // Tracked cull sites (StaticProgram, outermost frame, first kCullTracked of them): per-lane bounds
   // lo <= lhs <= hi on the site's test value lhs = slope |p - c| - K at THIS point, carried over from its
   // last full test through the known movement of the point (Scene::eval_near).  NaN = unknown.
@@ -255,6 +317,60 @@ RM_DEV bool cull_min_tracked(S& s, const PT& P, int a0) {
   float lhs = cull_min_lhs(s, P, a0);
   s.cull_lo[T] = lhs; s.cull_hi[T] = lhs;
   return __all(lhs >= s.acc);
+}
+
+// Wave-wide max / min of a per-lane float through DPP (no LDS traffic, ~7 VALU instructions): Hillis-Steele inside
+// every row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a source keep their own value), then row_bcast:15 and
+// row_bcast:31 carry the row results to lane 63.  NaN operands are ignored (IEEE maxNum / minNum).  Needs every lane of
+// the wave active -- true wherever a scene is evaluated (lanes past the end of the work run on clamped indices; the
+// ray pools give their idle lanes a copy of an active lane's ray).
+#define RM_DPP_F(x, ctrl, row_mask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (x)), __builtin_bit_cast(int, (x)), (ctrl), (row_mask), 0xf, false))
+template <bool kMax>
+RM_DEV float wave_reduce(float v) {
+  auto comb = [](float a, float b) { return kMax ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
+  v = comb(v, RM_DPP_F(v, 0x111, 0xf));   // row_shr:1
+  v = comb(v, RM_DPP_F(v, 0x112, 0xf));   // row_shr:2
+  v = comb(v, RM_DPP_F(v, 0x114, 0xf));   // row_shr:4
+  v = comb(v, RM_DPP_F(v, 0x118, 0xf));   // row_shr:8   -> lane 15 of every row holds the row's result
+  v = comb(v, RM_DPP_F(v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+  v = comb(v, RM_DPP_F(v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Exact culling inside a smooth union (RM_OP_SMOOTH_BEGIN with a bound table, RM_OP_CULL_LSE).
+// torch.logsumexp(-k d) = log(sum_i exp(x_i - m)) + m with x_i = -k d_i, m = max x.  exp(x) is EXACTLY +0.0f below
+// x = -103.98 (the smallest fp32 subnormal is e^-103.28; rm_math.h: exp_f64path; MKL's exp rounds to zero there too),
+// so a child with  k (d_i - d_min) > 104  adds an exact zero to the sum, is not the maximum, and has softmax weight
+// exactly 0 in the VJP: leaving it out changes no bit of the value or of any gradient.  Which children those are is
+// decided for the whole wave at once, one child per LANE: lane (base + j) reads child j's bounds
+//     slope_lb |p - c| - K_lb  <=  child_j(p)  <=  slope_ub |p - c| + K_ub       (subtree_bound, margins folded in)
+// and evaluates them on the ball (c0, rho) that holds the points of all 64 rays; d_min <= min_j ub_j, and child j is
+// skipped when  k (lb_j - min ub) > 105 (+ the rounding of the products): ~45 instructions per evaluation whatever
+// the number of children.  Returns the skip bits at the children's tape slots.
+template <class S, class PT>
+RM_DEV unsigned long long lse_cull_mask(const S& s, const PT& P, int koff, int table, int base, int n) {
+  const int lane = threadIdx.x & 63;
+  const float k = P[koff];
+  const V3 c0 = mk3(uniform_f(s.p.x), uniform_f(s.p.y), uniform_f(s.p.z));
+  const V3 d0 = s.p - c0;
+  const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(d0.z, d0.z, __builtin_fmaf(d0.y, d0.y, d0.x * d0.x)));
+  // (a lane whose point is NaN is left out: its value is NaN whichever children are skipped, the nearest one never is)
+  const float rho = __builtin_fmaf(wave_reduce<true>(r), 1.0001f, 1e-6f * ((fabsf(c0.x) + fabsf(c0.y)) + fabsf(c0.z)) + 1e-6f);
+  const int j = lane - base;
+  const bool mine = (j >= 0) & (j < n);
+  const float4* e = reinterpret_cast<const float4*>(s.lds + table + 8 * (mine ? j : 0));
+  const float4 ea = e[0], eb = e[1];                 // {cx, cy, cz, slope_lb}, {K_lb, slope_ub, K_ub, -}
+  const V3 dc = c0 - mk3(ea.x, ea.y, ea.z);
+  const float t = __builtin_amdgcn_sqrtf(__builtin_fmaf(dc.z, dc.z, __builtin_fmaf(dc.y, dc.y, dc.x * dc.x)));
+  const float lb = __builtin_fmaf(ea.w, __builtin_fmaxf(__builtin_fmaf(t, 0.99999f, -rho), 0.0f), -eb.x);   // K_lb = NaN: unbounded child
+  float ub = __builtin_fmaf(eb.y, __builtin_fmaf(t, 1.00001f, rho), eb.z);                                   // +inf: no upper bound known
+  ub = mine ? ub : __builtin_inff();
+  const float dmin_ub = wave_reduce<false>(ub);
+  // x_i - m is formed from rounded products: 2^-23 relative of either term, covered by the last term of the threshold
+  const float thr = __builtin_fmaf(1e-6f * fabsf(k), fabsf(lb) + fabsf(dmin_ub), 105.0f);
+  const bool cull = mine & (k > 0.0f) & (k * (lb - dmin_ub) > thr);          // NaN anywhere: false
+  return __ballot(cull);
 }
 
 template <class S, class PT>
@@ -313,7 +429,8 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       s.d = s.acc;
       s.sp -= 1; s.acc = s.st->ld(s.sp);
       break;
-    case RM_OP_SMOOTH_BEGIN:
+    case RM_OP_SMOOTH_BEGIN:   // a0 = bound table (0: none), a1 = first tape slot << 8 | children
+      if (a0 > 0) s.culled |= lse_cull_mask(s, P, off, a0, a1 >> 8, a1 & 255);
       break;
     case RM_OP_FOLD_LSE:  // children are kept on the tape; the reduction is two-pass like torch.logsumexp
       s.st->st(s.tape0 + a0, s.d);
@@ -321,7 +438,10 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
     case RM_OP_SMOOTH_END: {  // -logsumexp(-k d)/k : max, sum exp(x - max), log + max, / (-k)
       float nk = -P[off];
       float m = -__builtin_inff();
-      for (int i = 0; i < a1; ++i) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
+      // children skipped by their CULL_LSE (bit at their tape slot): exact zeros of the sum, never the maximum
+      auto skipped = [&](int i) { return (a0 + i < 64) && ((s.culled >> (a0 + i)) & 1ull); };
+      for (int i = 0; i < a1; ++i)
+        if (!skipped(i)) m = t_max(m, s.st->ld(s.tape0 + a0 + i) * nk);
       float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
       float L;
       if (s.record) {
@@ -331,11 +451,13 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
         // come through here: s.record is false for them.
         float sum = 0.0f;
         for (int i = 0; i < a1; ++i)
-          sum = sum + __builtin_amdgcn_exp2f((s.st->ld(s.tape0 + a0 + i) * nk - mm) * 1.44269504088896340736f);
+          if (!skipped(i)) sum = sum + __builtin_amdgcn_exp2f((s.st->ld(s.tape0 + a0 + i) * nk - mm) * 1.44269504088896340736f);
         L = __builtin_amdgcn_logf(sum) * 0.693147180559945309417f + mm;
         s.st->st(s.tape0 + a0 + a1, L);                 // the reverse pass starts from it (slot after the children)
       } else {
-        const float sum = aten_inner_sum(a1, [&](int i) { return rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm); });
+        const float sum = aten_inner_sum(a1, [&](int i) {
+          return skipped(i) ? 0.0f : rm_exp(s.st->ld(s.tape0 + a0 + i) * nk - mm);
+        });
         L = rm_log(sum) + mm;
       }
       s.d = L / nk;
@@ -350,6 +472,36 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
     default:
       break;
   }
+}
+
+// SMOOTH_END with compile-time slot range (StaticProgram): the same arithmetic as the case in fwd_op, every tape
+// index a constant.  A child whose bit is set in `culled` was skipped by its CULL_LSE: its term is exactly +0.0f and it
+// cannot be the maximum (lse_cull_mask), so it is left out of both passes.
+template <int A0, int N, bool kCulled, class S, class PT>
+RM_DEV void smooth_end_static(S& s, const PT& P, int off) {
+  const float nk = -P[off];
+  // (kCulled = false -- no bound table on this union's SMOOTH_BEGIN -- leaves straight-line code without a branch per child)
+  auto skipped = [&](int i) { return kCulled && (A0 + i < 64) && ((s.culled >> (A0 + i)) & 1ull); };
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (!skipped(i)) m = t_max(m, s.st->ld(s.tape0 + A0 + i) * nk);
+  const float mm = (fabsf(m) == __builtin_inff()) ? 0.0f : m;
+  float L;
+  if (s.record) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (!skipped(i)) sum = sum + __builtin_amdgcn_exp2f((s.st->ld(s.tape0 + A0 + i) * nk - mm) * 1.44269504088896340736f);
+    L = __builtin_amdgcn_logf(sum) * 0.693147180559945309417f + mm;
+    s.st->st(s.tape0 + A0 + N, L);
+  } else {
+    const float sum = aten_inner_sum_n<N>([&](int i) {
+      return skipped(i) ? 0.0f : rm_exp(s.st->ld(s.tape0 + A0 + i) * nk - mm);
+    });
+    L = rm_log(sum) + mm;
+  }
+  s.d = L / nk;
 }
 
 // --------------------------------------------------------------------------
@@ -558,6 +710,10 @@ struct RuntimeProgram {
         }
         continue;
       }
+      if (op == RM_OP_CULL_LSE) {            // a0 = tape slot of the child, a1 = instructions up to and including its FOLD_LSE
+        if ((s.culled >> a0) & 1ull) pc += a1;
+        continue;
+      }
       fwd_op(s, P, op, off, a0, a1);
     }
   }
@@ -569,6 +725,11 @@ struct RuntimeProgram {
       if (op == RM_OP_FOLD_MIN && a1 > 0 && ((s.culled >> a0) & 1ull)) {   // a1 = distance back to its CULL_MIN
         s.g = 0.0f;
         pc -= a1;                              // jump over the skipped child and its CULL_MIN
+        continue;
+      }
+      if (op == RM_OP_FOLD_LSE && a1 > 0 && ((s.culled >> a0) & 1ull)) {   // softmax weight exactly 0: nothing flows into the child
+        s.g = 0.0f;
+        pc -= a1;
         continue;
       }
       bwd_op(s, P, op, off, a0, a1);
@@ -597,6 +758,15 @@ struct StaticProgram {
     return k;
   }
   static constexpr int kTracked = count_tracked();
+  // does the smooth union that ends at `pc` carry a bound table (exact culling of its children, RM_OP_CULL_LSE)?
+  static constexpr bool smooth_culled(int pc) {
+    int depth = 0;
+    for (int i = pc; i >= 0; --i) {
+      if (Code::code[i].op == RM_OP_SMOOTH_END) ++depth;
+      if (Code::code[i].op == RM_OP_SMOOTH_BEGIN && --depth == 0) return Code::code[i].a0 != 0;
+    }
+    return false;
+  }
   // executes instructions [PC, END)
   template <int PC, int END, class S, class PT>
   RM_DEV void fwd_range(S& s, const PT& P) const {
@@ -613,6 +783,12 @@ struct StaticProgram {
           fwd_range<PC + 1, PC + 1 + skip>(s, P);
         }
         fwd_range<PC + 1 + skip, END>(s, P);
+      } else if constexpr (i.op == RM_OP_CULL_LSE) {
+        if (!((s.culled >> i.a0) & 1ull)) fwd_range<PC + 1, PC + 1 + i.a1>(s, P);
+        fwd_range<PC + 1 + i.a1, END>(s, P);
+      } else if constexpr (i.op == RM_OP_SMOOTH_END) {
+        smooth_end_static<i.a0, i.a1, smooth_culled(PC)>(s, P, i.off);
+        fwd_range<PC + 1, END>(s, P);
       } else {
         fwd_op(s, P, i.op, i.off, i.a0, i.a1);
         fwd_range<PC + 1, END>(s, P);
@@ -624,16 +800,16 @@ struct StaticProgram {
   RM_DEV void bwd_range(S& s, const PT& P) const {
     if constexpr (PC > BEGIN) {
       constexpr Ins i = Code::code[PC];
-      if constexpr (i.op == RM_OP_FOLD_MIN && i.a1 > 0) {
+      if constexpr ((i.op == RM_OP_FOLD_MIN || i.op == RM_OP_FOLD_LSE) && i.a1 > 0) {
         if ((s.culled >> i.a0) & 1ull) {
           s.g = 0.0f;
         } else {
           bwd_op(s, P, i.op, i.off, i.a0, i.a1);
-          bwd_range<PC - 1, PC - i.a1>(s, P);     // the child; PC - a1 is its CULL_MIN
+          bwd_range<PC - 1, PC - i.a1>(s, P);     // the child; PC - a1 is its CULL_MIN / CULL_LSE
         }
         bwd_range<PC - i.a1 - 1, BEGIN>(s, P);
       } else {
-        if constexpr (i.op != RM_OP_CULL_MIN) bwd_op(s, P, i.op, i.off, i.a0, i.a1);
+        if constexpr (i.op != RM_OP_CULL_MIN && i.op != RM_OP_CULL_LSE) bwd_op(s, P, i.op, i.off, i.a0, i.a1);
         bwd_range<PC - 1, BEGIN>(s, P);
       }
     }
@@ -652,6 +828,7 @@ struct Scene {
   Store* st;
   int tape0;   // store index of tape slot 0 (= stack_floats)
   int acc0;    // store index of gradient accumulator 0 (= stack_floats + n_slots)
+  const float* lds = nullptr;   // staged parameter block (raw + derived) in LDS: per-lane table reads of lse_cull_mask
 
   // bounds of the tracked cull sites at the point of the previous evaluation (per lane; NaN = unknown)
   mutable float cull_lo[kCullTracked] = {}, cull_hi[kCullTracked] = {};   // meaningful after the first evaluation (move = NaN)
@@ -661,7 +838,7 @@ struct Scene {
   RM_DEV float eval_near(V3 p, float move, bool record = false) const {
     Fwd<Store> s;
     s.p = p; s.d = 0.0f; s.acc = __builtin_inff(); s.sp = 0; s.tape0 = tape0; s.st = st; s.record = record;
-    s.culled = 0ull;
+    s.culled = 0ull; s.lds = lds;
 #pragma unroll
     for (int k = 0; k < Prog::kTracked; ++k) {
       // move = NaN (nothing known: first evaluation of a tile, every 16th step) turns both bounds into NaN
@@ -679,7 +856,7 @@ struct Scene {
   RM_DEV V3 vjp(V3 p, float g, float* value = nullptr) const {
     Fwd<Store> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
-    f.culled = 0ull;
+    f.culled = 0ull; f.lds = lds;
 #pragma unroll
     for (int k = 0; k < Prog::kTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
     prog.forward(f, P);
@@ -694,7 +871,7 @@ struct Scene {
   RM_DEV V3 vjp_point(V3 p, float g, float* value = nullptr) const {
     Fwd<Store> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
-    f.culled = 0ull;
+    f.culled = 0ull; f.lds = lds;
 #pragma unroll
     for (int k = 0; k < Prog::kTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
     prog.forward(f, P);
@@ -731,37 +908,51 @@ constexpr int kBoundDepth = 12;
 // slope < 1 comes from affine nodes whose quaternion is not unit: the reference applies
 // V + w t + qv x t, t = 2 qv x V (quaternion.py:55-72) without normalising, which for q = |q| u is the
 // normal matrix M = (1 - s) I + s R_u, s = |q|^2, whose smallest singular value is min(1, 2 s - 1).
+// Also an UPPER bound around the same centre,  subtree(p) <= uslope |p - c| + Ru  (out[5] = Ru, out[6] = uslope; Ru = +inf
+// when none is known): every primitive here is an exact distance (or, inside, minus one), so |d(p)| is the distance
+// to the surface, which lies inside the sphere (c, R): d(p) <= |p - c| + R.  Rounding subtracts at most max(-r, 0),
+// the onion |d| - r satisfies |d| <= uslope |p - c| + max(Ru, R); an affine frame stretches distances by at most the
+// largest singular value max(1, 2 s - 1) of M.  Unions and smooth unions give none (min / -lse of the children's bounds
+// would need one sphere per child); it is only used for the nearest-child estimate of lse_cull_mask.
 template <class GetIns>
-RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float* out /*[5]*/, BoundFrame* st) {
+RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float* out /*[7]*/, BoundFrame* st) {
   constexpr int kDepth = kBoundDepth;
   int sp = 0;
   float cx = 0.0f, cy = 0.0f, cz = 0.0f, R = __builtin_inff(), slope = 1.0f;
+  float Ru = __builtin_inff(), uslope = 1.0f;
   const float inf = __builtin_inff();
   bool overflow = false;
   for (int pc = begin; pc < end && !overflow; ++pc) {
     const int4 w = ins(pc);
     const int op = w.x, off = w.y;
     switch (op) {
-      case RM_OP_SPHERE: cx = cy = cz = 0.0f; slope = 1.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_SPHERE: cx = cy = cz = 0.0f; slope = uslope = 1.0f; R = Ru = (P[off] >= 0.0f) ? P[off] : inf; break;
       case RM_OP_BOX: {
         float hx = P[off], hy = P[off + 1], hz = P[off + 2];
-        cx = cy = cz = 0.0f; slope = 1.0f;
-        R = (hx >= 0.0f && hy >= 0.0f && hz >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) : inf;
+        cx = cy = cz = 0.0f; slope = uslope = 1.0f;
+        R = Ru = (hx >= 0.0f && hy >= 0.0f && hz >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) : inf;
       } break;
-      case RM_OP_PLANE: slope = 1.0f; R = inf; break;
+      case RM_OP_PLANE: slope = uslope = 1.0f; R = Ru = inf; break;
       case RM_OP_LINE: {   // capsule: sphere around the midpoint of AB
         const float* a = P + off;
         cx = 0.5f * (a[0] + a[3]); cy = 0.5f * (a[1] + a[4]); cz = 0.5f * (a[2] + a[5]);
         float hx = 0.5f * (a[3] - a[0]), hy = 0.5f * (a[4] - a[1]), hz = 0.5f * (a[5] - a[2]);
-        slope = 1.0f;
-        R = (a[6] >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) * 1.00001f + a[6] : inf;
+        slope = uslope = 1.0f;
+        R = Ru = (a[6] >= 0.0f) ? sqrtf(hx * hx + hy * hy + hz * hz) * 1.00001f + a[6] : inf;
       } break;
-      case RM_OP_DISK: cx = cy = cz = 0.0f; slope = 1.0f; R = (P[off] >= 0.0f) ? P[off] : inf; break;
+      case RM_OP_DISK: cx = cy = cz = 0.0f; slope = uslope = 1.0f; R = Ru = (P[off] >= 0.0f) ? P[off] : inf; break;
       case RM_OP_TORUS:
-        cx = cy = cz = 0.0f; slope = 1.0f;
-        R = (P[off] >= 0.0f && P[off + 1] >= 0.0f) ? P[off] + P[off + 1] : inf;
+        cx = cy = cz = 0.0f; slope = uslope = 1.0f;
+        R = Ru = (P[off] >= 0.0f && P[off + 1] >= 0.0f) ? P[off] + P[off + 1] : inf;
         break;
-      case RM_OP_ROUND: case RM_OP_ONION: R += fmaxf(P[off], 0.0f); break;     // d - r, |d| - r >= d - max(r,0)
+      case RM_OP_ROUND:                                                         // d - r <= ub + max(-r, 0)
+        Ru += fmaxf(-P[off], 0.0f);
+        R += fmaxf(P[off], 0.0f);                                               // d - r >= d - max(r, 0)
+        break;
+      case RM_OP_ONION:                                                         // |d| <= uslope |p - c| + max(Ru, R)  (d >= -R)
+        Ru = fmaxf(Ru, R) + fmaxf(-P[off], 0.0f);
+        R += fmaxf(P[off], 0.0f);                                               // |d| - r >= d - max(r, 0)
+        break;
       case RM_OP_AFFINE_PUSH:
         if (sp >= kDepth) { overflow = true; break; }
         st[sp].n = -1; st[sp].off = off; ++sp;
@@ -773,7 +964,7 @@ RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float*
         V3 qv = mk3(a[4], a[5], a[6]);
         float s2 = ((w4 * w4 + qv.x * qv.x) + qv.y * qv.y) + qv.z * qv.z;
         float sigma = fminf(1.0f, 2.0f * s2 - 1.0f) - 1e-5f;           // smallest singular value of M, rounded down
-        if (!(sigma > 0.5f) || !(s2 < 4.0f)) { R = inf; break; }
+        if (!(sigma > 0.5f) || !(s2 < 4.0f)) { R = Ru = inf; break; }
         // child(y) >= slope |y - c| - R.  Take c' = M'(c) (M' = qrot(., q); exactly M^-1 only for unit q) and
         // measure the miss e = |M c' - c|:  |y - c| >= |M (p - t - c')| - e >= sigma |p - (t + c')| - e.
         V3 c0 = mk3(cx, cy, cz);
@@ -783,6 +974,9 @@ RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float*
         cx = c1.x + a[0]; cy = c1.y + a[1]; cz = c1.z + a[2];
         R = (R + e) * 1.0001f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
         slope = slope * sigma;
+        // upper bound: |M (p - t) - c| <= smax |p - (t + c')| + e,  smax = max(1, 2 s - 1) rounded up
+        Ru = (Ru + uslope * e) * 1.0001f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+        uslope = uslope * (fmaxf(1.0f, 2.0f * s2 - 1.0f) + 1e-5f);
       } break;
       case RM_OP_UNION_BEGIN: case RM_OP_SMOOTH_BEGIN:
         if (sp >= kDepth) { overflow = true; break; }
@@ -811,17 +1005,20 @@ RM_DEV void subtree_bound(GetIns ins, const float* P, int begin, int end, float*
       } break;
       case RM_OP_UNION_END:
         --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; slope = st[sp].slope;
+        Ru = inf; uslope = 1.0f;
         break;
       case RM_OP_SMOOTH_END: {   // -lse(-k d)/k >= min d - log(n)/k  for k > 0
         --sp; cx = st[sp].cx; cy = st[sp].cy; cz = st[sp].cz; R = st[sp].R; slope = st[sp].slope;
+        Ru = inf; uslope = 1.0f;
         float k = P[off];
         R = (k > 0.0f) ? R + logf((float)st[sp].n) / k : inf;
       } break;
-      default: break;            // nested CULL_MIN: no effect on the bound
+      default: break;            // nested CULL_MIN / CULL_LSE: no effect on the bound
     }
   }
   if (overflow || !(R == R) || !(slope > 0.5f)) R = inf;
-  out[0] = cx; out[1] = cy; out[2] = cz; out[3] = R; out[4] = slope;
+  if (overflow || !(Ru == Ru) || !(uslope >= 1.0f) || !(uslope < 8.0f)) Ru = inf;
+  out[0] = cx; out[1] = cy; out[2] = cz; out[3] = R; out[4] = slope; out[5] = Ru; out[6] = uslope;
 }
 
 // Derived constants of one instruction (capsule AB and AB/|AB|^2, primitives.py:52-54; bounding sphere
@@ -847,9 +1044,27 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
   if (threadIdx.x == 0) {     // bounding spheres: few, tiny, one after the other on one thread
     for (int pc = 0; pc < n_instr; ++pc) {
       const int4 w = ins(pc);
+      if (w.x == RM_OP_CULL_LSE) {
+        // bound table entry of a smooth-union child (lse_cull_mask): {cx, cy, cz, slope_lb, K_lb, slope_ub, K_ub, 0},
+        // the lower bound with the margins of CULL_MIN, the upper one with the same ones on the other side
+        float b[7];
+        subtree_bound(ins, s_params, pc + 1, pc + w.w, b, s_bound_stack);          // child without its FOLD_LSE
+        float* out = s_params + w.y;
+        const float c1 = (fabsf(b[0]) + fabsf(b[1])) + fabsf(b[2]);
+        const float Kl = ((b[3] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
+        const float Ku = ((b[5] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
+        out[0] = b[0]; out[1] = b[1]; out[2] = b[2];
+        out[3] = b[4] - 2e-4f;
+        out[4] = Kl < __builtin_inff() ? Kl : __builtin_nanf("");
+        out[5] = b[6] + 2e-4f;
+        out[6] = Ku < __builtin_inff() ? Ku : __builtin_inff();
+        out[7] = 0.0f;
+      }
       if (w.x == RM_OP_CULL_MIN) {
+        float b7[7];
         float* out = s_params + w.z;
-        subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), out, s_bound_stack);  // child without its FOLD
+        subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), b7, s_bound_stack);  // child without its FOLD
+        for (int q = 0; q < 5; ++q) out[q] = b7[q];
         // cull_min_test:  (slope - 2e-4) dist - K >= acc  with  K = 1.0001 R + 1e-4 : the bound with a margin of
         // 1e-4 (1 + 2 dist + R), three orders of magnitude above the fp32 rounding of the child's own value
         // (+ 1e-5 |c|_1: rounding drift of p over the <= 16 steps a tracked bound is carried, eval_near)

@@ -28,7 +28,7 @@ struct GenericCfg {
   using Prog = RuntimeProgram;
   using SceneT = Scene<Prog, Store, LdsParams>;
   static constexpr bool kStatic = false;
-  static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_derived; }
+  static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_grad_derived; }
 
   // returns the scene context; `store` must outlive it
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool scalar_fetch = false) {
@@ -47,6 +47,7 @@ struct GenericCfg {
     s.prog.code = scalar_fetch ? reinterpret_cast<const int4*>(sc.program) : s_prog;
     s.prog.n = sc.n_instr;
     s.P.p = s_params;
+    s.lds = s_params;
     s.st = &store;
     s.tape0 = sc.stack_floats;
     s.acc0 = sc.stack_floats + sc.n_slots;
@@ -54,11 +55,15 @@ struct GenericCfg {
   }
 };
 
-// Compile-time scene: Code supplies n, code[], n_params, n_derived, stack_floats, n_slots.
+// Compile-time scene: Code supplies n, code[], n_params, n_derived, n_grad_derived, stack_floats, n_slots.
+#ifndef RM_LDS_TAPE_MIN_SLOTS
+#define RM_LDS_TAPE_MIN_SLOTS 17   // scenes with at least this many tape slots keep the tape in LDS columns (HybridStore)
+#endif
 template <class Code, int kRegParamLimit = 64>
 struct StaticCfg {
-  static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_derived;
-  using Store = RegStore<kStoreN>;
+  static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_grad_derived;
+  static constexpr bool kLdsTape = Code::n_slots >= RM_LDS_TAPE_MIN_SLOTS;
+  using Store = std::conditional_t<kLdsTape, HybridStore<Code::stack_floats, Code::n_slots, kStoreN>, RegStore<kStoreN>>;
   using Prog = StaticProgram<Code>;
   // small parameter blocks ride in registers; big ones (config 5: 381 floats) stay in LDS
   static constexpr int kParamFloats = Code::n_params + Code::n_derived;
@@ -66,18 +71,26 @@ struct StaticCfg {
   using PT = std::conditional_t<kRegParams, RegParams<kParamFloats>, LdsParams>;
   using SceneT = Scene<Prog, Store, PT>;
   static constexpr bool kStatic = true;
-  static constexpr int kAcc = Code::n_params + Code::n_derived;
+  static constexpr int kAcc = Code::n_params + Code::n_grad_derived;     // gradient accumulators per ray
   static RM_DEV int n_acc(const RmScene&) { return kAcc; }
 
-  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool = false) {
+  // floats of the block's tape area (after the parameter block and, in backward kernels, the reduction scratch)
+  static constexpr int kTapeFloats = kLdsTape ? Code::n_slots * kLdsTapeStride : 0;
+
+  static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool backward = false) {
     // the parameter block is still staged through LDS (raw + derived), the program is not
     float* s_params = smem;
+    if constexpr (kLdsTape) {
+      const int pb = (Code::n_params + Code::n_derived + 3) & ~3;
+      store.base = smem + pb + 4 + (backward ? (int)(blockDim.x >> 6) * kAcc : 0) + threadIdx.x;
+    }
     stage_params(sc, s_params, Code::n_params);
     __syncthreads();
     auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
     derive_constants(ins, Code::n, s_params);
     SceneT s;
     if constexpr (kRegParams) s.P.load(s_params); else s.P.p = s_params;
+    s.lds = s_params;
     s.st = &store;
     s.tape0 = Code::stack_floats;
     s.acc0 = Code::stack_floats + Code::n_slots;
@@ -1229,20 +1242,37 @@ __global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
     if (__any(act && k >= RM_PRIO_REGEN)) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
 #endif
-    if (act) {
-      V3 prev = p;
+    const unsigned long long actm = __ballot(act);
+    if (actm) {
+      // The scene is evaluated with EVERY lane of the wave active (the wave-wide reductions of lse_cull_mask need
+      // that): a lane without a marching ray shadows the first active lane's ray -- the same point, hence the same
+      // votes in every wave-uniform cull test and no influence on the bounds -- and throws the result away.
+      const int src = __builtin_ctzll(actm);
+      auto from = [&](float x) {
+        return act ? x : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+      };
+      V3 pe = mk3(from(p.x), from(p.y), from(p.z));
+      const V3 ve = mk3(from(v.x), from(v.y), from(v.z));
+      const float vne = from(vn);
+      float movee = from(move);
+      V3 prev = pe;
       for (int j = 0; j < 4; ++j) {
-        const float f = scene.eval_near(p, ((it + j) & 15) ? move : __builtin_nanf(""));
-        move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
-        prev = p;
-        p = step_point(p, v, f);
+        const float f = scene.eval_near(pe, ((it + j) & 15) ? movee : __builtin_nanf(""));
+        movee = __builtin_fmaf(fabsf(f), vne, 4e-6f);
+        prev = pe;
+        pe = step_point(pe, ve, f);
       }
-      k += 4;
-      if (lambda == 0) {
-        const int found = same_bits(p, prev) ? 1 : (same_bits(p, snap) ? (k - snap_step) : 0);
-        if (found) { lambda = found; stop = k + (S - k) % found; }
+      if (act) {
+        p = pe; move = movee;
+        k += 4;
+        if (lambda == 0) {
+          const int found = same_bits(p, prev) ? 1 : (same_bits(p, snap) ? (k - snap_step) : 0);
+          if (found) { lambda = found; stop = k + (S - k) % found; }
+        }
+        if (k == next_snap) { snap = p; snap_step = k; next_snap <<= 1; }
+      } else {
+        move = __builtin_nanf("");      // the tracked cull bounds now describe the shadowed ray, not this lane's next one
       }
-      if (k == next_snap) { snap = p; snap_step = k; next_snap <<= 1; }
     }
     it += 4;
   }
@@ -1933,7 +1963,7 @@ __global__ void k_reduce_partials(const float* __restrict__ partials, int nblock
 // (AB = end - start, ABs = AB / |AB|^2; primitives.py:52-54) and emit the raw-parameter vector.
 __global__ void k_finish_grads(RmScene sc, const float* __restrict__ sums, float* __restrict__ grad_params) {
   extern __shared__ float s_acc[];
-  const int n_acc = sc.n_params + sc.n_derived;
+  const int n_acc = sc.n_params + sc.n_grad_derived;
   for (int i = threadIdx.x; i < n_acc; i += blockDim.x) s_acc[i] = sums[i];
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -123,3 +123,30 @@ def spec_has(spec, kind):
     kids = spec[2] if len(spec) > 2 else []
     kids = kids if isinstance(kids, list) else [kids]
     return any(spec_has(c, kind) for c in kids)
+
+
+def random_blob_spec(gen, n_min=8, n_max=40):
+    """A smooth union of many affine-placed random subtrees spread widely enough (relative to 104 / blend_k) that the
+    exact logsumexp culling (RM_OP_CULL_LSE) finds children to skip, optionally inside a room and next to other
+    nodes.  Oracle spec; `gen` is a torch.Generator."""
+    def u(lo, hi, n=None):
+        x = torch.rand(n or 1, generator=gen) * (hi - lo) + lo
+        return x if n else x[0]
+
+    k = float(u(3.0, 60.0))
+    n = int(torch.randint(n_min, n_max + 1, (1,), generator=gen))
+    spread = float(u(0.4, 3.0)) * 104.0 / k
+    kids = []
+    for _ in range(n):
+        q = torch.nn.functional.normalize(torch.randn(4, generator=gen), dim=0) * u(0.93, 1.07)
+        child = random_spec(gen, depth=2, max_depth=4)
+        kids.append(("affine", {"translation": u(-spread, spread, 3), "orientation": q}, child))
+    blob = ("smooth_union", {"blend_k": torch.tensor(k)}, kids)
+    form = int(torch.randint(0, 3, (1,), generator=gen))
+    if form == 0:
+        return blob, spread
+    if form == 1:
+        room = ("onion", {"radius": torch.tensor(0.1)}, ("box", {"halfsides": torch.full((3,), 2.5 * spread + 3.0)}))
+        return ("union", {}, [room, blob]), spread
+    q = torch.nn.functional.normalize(torch.randn(4, generator=gen), dim=0)
+    return ("union", {}, [("affine", {"translation": u(-1.0, 1.0, 3), "orientation": q}, blob), random_spec(gen, depth=2)]), spread

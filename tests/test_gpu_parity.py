@@ -358,12 +358,18 @@ def test_static_and_generic_agree_bitwise(monkeypatch):
 
 def test_config5_scene_vs_golden_and_host_spread():
     """32-primitive smooth-union scene (config 5 shape, small frame) against the reference's output from the
-    build container (fixture f9) -- and, next to it, how far the SAME reference arithmetic lands from that
-    fixture when it runs on this box's CPU (oracle = the reference's ATen op stream; its logsumexp is MKL VML,
-    which is CPU-dispatched).  A few rays graze a blend crease where one ulp of exp() decides which object
-    they end on, so 1e-5 cannot hold for every pixel of ANY two evaluations that are not the same binary on the
-    same CPU; the device (correctly rounded exp/log, host independent) has to be no further from the
-    fixture than the reference is from itself."""
+    build container (fixture f9).  Two legs:
+
+    * `restated` -- the oracle with exp / log of oracle/rm_math_ref.c (two restatements by the same author, tied to
+      torch through the exhaustive sweep's <= 1-ulp counts, tests/test_math_sweep.py): the device must agree bit for
+      bit at every pixel.  That pins everything but MKL's ulps: 128 steps x 32 affine primitives, ATen's summation order
+      inside logsumexp, the culling, the early-out.
+    * the reference fixture itself (MKL VML exp / log, CPU-dispatched): every device value is within north_star's 1e-5
+      of it, OR the pixel is one the reference ITSELF cannot resolve to 1e-5 -- its own float32 and float64 renders
+      of the frame (both in the fixture) differ by more than 1e-5 there: a ray grazing a blend crease, where one ulp
+      of exp() decides which object it ends on.  The pixels that may differ are thus named by the reference, not by
+      a flat budget; their number is printed.  The same rule for p_final.
+    Next to it, how far the SAME reference arithmetic lands from the fixture on this box's CPU (informational)."""
     from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
     g = H.gold("f9_many32_54x96_s128.npz")
     h, w = (int(x) for x in g["hw"]); steps = int(g["steps"])
@@ -371,28 +377,37 @@ def test_config5_scene_vs_golden_and_host_spread():
     q, t = torch.from_numpy(g["q"]), torch.from_numpy(g["t"])
     bufs = O.camera_buffers(1, w, h, H.PX * h, H.PX * w, H.PX * h)
     spec = O.scene_many(32)
+    tol = 1e-5
+
+    def excused_or_close(got, want32, want64, what):
+        """per element: |got - want32| <= tol, or the reference's own fp32-vs-fp64 spread at that PIXEL exceeds tol"""
+        got = got.detach().cpu().double().numpy()
+        err = np.abs(got - want32.astype(np.float64))
+        spread = np.abs(want32.astype(np.float64) - want64).max(axis=-1, keepdims=True)     # per pixel
+        ill = np.broadcast_to(spread > tol, err.shape)
+        assert np.isfinite(got).all() and np.isfinite(want64).all(), what
+        off = err > tol
+        print(f"config5 {what}: max|err|={err.max():.3g}; {int(off.sum())} of {err.size} values beyond {tol:g}, "
+              f"{int((off & ~ill).sum())} of them on pixels the reference resolves; reference fp32-vs-fp64 spread > {tol:g} "
+              f"on {int((spread > tol).sum())} of {spread.size} pixels")
+        assert not (off & ~ill).any(), (what, float(err[off & ~ill].max()))
+        return int(off.sum())
+
     with torch.no_grad():
         pos, frames, _, dirs = loop.camera(q.to(DEV), t.to(DEV))
-        p_err = H.report("p", loop.marcher(pos, dirs, steps), g["p"])
-    print(f"config5 scene p_final vs fixture: max|err|={p_err[0]:.3g} frac>1e-5={p_err[1]:.3g}")
+        excused_or_close(loop.marcher(pos, dirs, steps), g["p"], g["p_f64"], "p_final")
     for mode in (0, 4):
         with torch.no_grad():
             host = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
             with O.math_mode("restated"):      # same op stream, exp/log of oracle/rm_math_ref.c: host independent
                 exact = O.render(spec, bufs, q, t, mode, 1, steps, H.EPS)
             got = loop(q.to(DEV), t.to(DEV), mode, 1, steps)
-        # everything but MKL's ulps is pinned bit for bit, at every pixel: 128 steps x 32 affine primitives,
-        # ATen's summation order inside logsumexp, the culling, the early-out
         assert H.report(f"config5 mode {mode} restated", got, exact)[0] == 0.0
         want = g[f"mode{mode}"]
         ch = want.shape[-1]
-        mx, frac = H.report(f"config5 mode {mode}", got[..., :ch], want)
+        excused_or_close(got[..., :ch], want, g[f"mode{mode}_f64"], f"mode {mode}")
         hmx, hfrac = H.report(f"config5 mode {mode} host", host[..., :ch], want)
-        print(f"config5 scene mode {mode}: device vs fixture max|err|={mx:.3g} frac>1e-5={frac:.3g}; "
-              f"this host's reference arithmetic vs fixture max|err|={hmx:.3g} frac>1e-5={hfrac:.3g}")
-        assert frac <= 1e-3 and mx <= 1e-3, (mode, mx, frac)
-        if hfrac > 0:          # a host whose MKL path differs from the fixture's: the yardstick
-            assert frac <= 2.0 * hfrac + 2e-4, (mode, frac, hfrac)
+        print(f"config5 scene mode {mode}: this host's reference arithmetic vs fixture max|err|={hmx:.3g} frac>1e-5={hfrac:.3g}")
 
 
 def test_two_camera_batch_vs_golden(kernel_path):

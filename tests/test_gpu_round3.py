@@ -1,5 +1,6 @@
 """GPU tests added in round 3: main.py's torch.compile line, the config-4 shape at full size, the fused
 normalisation VJP kernel, the training-step helper."""
+import os
 import warnings
 
 import pytest
@@ -53,3 +54,75 @@ def test_main_py_torch_compile_line_is_inert():
     pts = torch.rand(4096, 3, device=DEV).half() * 4 - 2
     with torch.no_grad():
         assert torch.equal(torch.compile(scene)(pts), scene(pts))
+
+
+@pytest.mark.parametrize("case", ["many32", "blob0", "blob1", "blob2", "blob3", "blob4", "blob5"])
+def test_smooth_union_culling_changes_no_bit(case, monkeypatch):
+    """CULL_LSE (a smooth-union child whose logsumexp term is exactly +0.0f for the whole wave is
+    skipped) is an exact optimisation: the same scene compiled with RM_CULL_LSE=0 and with it gives identical values,
+    point gradients, parameter gradients and frames -- through the interpreter, and (many32) through the specialised
+    kernels, whose tape lives in LDS columns."""
+    from ray_marching_amd import _abi, ops
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
+    monkeypatch.setattr(ops, "bwd_hard_capacity", 0)      # bitwise parameter gradients: no atomically ordered deferred-ray list
+    monkeypatch.setenv("RM_CULL_LSE_MIN", "2")
+    monkeypatch.setenv("RM_SPECIALIZE", "off")
+    gen = torch.Generator().manual_seed(4242 + sum(map(ord, case)))
+    if case == "many32":
+        make, spread = (lambda: make_many_primitive_scene(32)), 3.0
+    else:
+        spec, spread = H.random_blob_spec(gen)
+        spec = O.map_spec(spec, lambda x: x.clone().float())
+        make = lambda: H.spec_to_module(spec)
+    pts = torch.cat([(torch.rand(64, 1, 3, generator=gen) * 2 - 1) * 2.5 * spread,
+                     (torch.rand(64, 1, 3, generator=gen) * 2 - 1) * 0.5 * spread])
+    pts = (pts + 0.02 * spread * torch.randn(128, 64, 3, generator=gen)).reshape(-1, 3).to(DEV)      # coherent waves
+    wts = torch.randn(pts.shape[0], 1, generator=gen).to(DEV)
+    same = lambda x, y: torch.equal(torch.nan_to_num(x, nan=1234.5), torch.nan_to_num(y, nan=1234.5)) \
+        and torch.equal(x.isnan(), y.isnan())
+    res = {}
+    for path in (("off", "jit") if case == "many32" else ("off",)):      # jit: hipcc builds the culled program's library (~15 s)
+        from ray_marching_amd import specialize
+        if path == "jit" and not os.path.exists(specialize._hipcc()):
+            continue
+        monkeypatch.setenv("RM_SPECIALIZE", path)
+        specialize._loaded.clear()
+        for cull in ("0", "1"):
+            monkeypatch.setenv("RM_CULL_LSE", cull)
+            module = make().to(DEV)
+            cs = compiled_for(module)
+            n_sites = int((cs.program.reshape(-1, 4)[:, 0] == _abi.OP_CULL_LSE).sum())
+            assert (n_sites > 0) == (cull == "1")
+            if path == "jit" and cull == "0":
+                continue          # the unculled program through the specialised kernels is what every other test runs
+            assert cs.specialised == (path == "jit")
+            p = pts.clone().requires_grad_(True)
+            d = module(p)
+            (d * wts).sum().backward()
+            gw = [None if x.grad is None else x.grad.clone() for x in module.parameters()]
+            loop = H.make_loop(module, 40, 72)
+            q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -1.5 * spread]], device=DEV)
+            with torch.no_grad():
+                frames = [loop(q, t, m, 1, 64) for m in (0, 4, 2, 5)]
+            for prm in module.parameters():
+                prm.grad = None
+            loop(q, t, 0, 1, 24).pow(2).mean().backward()
+            res[(path, cull)] = dict(d=d.detach(), gp=p.grad, frames=frames, gw=gw,
+                                     gf=[None if x.grad is None else x.grad.clone() for x in module.parameters()])
+    ref = res[("off", "0")]
+    for key, got in res.items():
+        if key == ("off", "0"):
+            continue
+        assert same(ref["d"], got["d"]) and same(ref["gp"], got["gp"]), key
+        for x, y in zip(ref["frames"], got["frames"]):
+            assert same(x, y), key
+        if key[0] == "off":           # same kernels, same block size class: parameter gradients to summation order
+            for name in ("gw", "gf"):
+                for x, y in zip(ref[name], got[name]):
+                    assert (x is None) == (y is None)
+                    if x is not None:
+                        scale = max(float(torch.nan_to_num(x).abs().max()), 1e-30)
+                        assert torch.equal(x.isnan(), y.isnan())
+                        assert float((torch.nan_to_num(x) - torch.nan_to_num(y)).abs().max()) <= 1e-4 * scale + 1e-9, (key, name)
+    specialize._loaded.clear()

@@ -195,3 +195,31 @@ def test_fp16_reference_path():
     assert d.max().item() <= 1e-2 and (d > 0).float().mean().item() < 0.01   # bit-exact up to host ATen differences
     # the reference's own fp16-vs-fp32 spread is large: fp16 parity can only be statistical
     assert float(g["ref_spread_p"]) > 0.1
+
+
+def test_config5_scene_fixture_and_its_float64_render():
+    """f9 (the 32-primitive smooth union of config 5, 54x96x128): the oracle in float64 reproduces the reference's own
+    float64 render held in the fixture, and the float32 oracle is within 1e-5 of the float32 fixture on every pixel
+    the reference resolves to 1e-5 -- i.e. where its float32 and float64 renders agree that closely (on the build
+    container's MKL it is bit-exact everywhere; the grazing-ray pixels are where another host's exp ulps may show)."""
+    g = load("f9_many32_54x96_s128.npz")
+    h, w = (int(x) for x in g["hw"]); steps = int(g["steps"])
+    q, t = torch.from_numpy(g["q"]), torch.from_numpy(g["t"])
+    bufs = O.camera_buffers(1, w, h, PX * h, PX * w, PX * h)
+    spec64 = O.map_spec(O.scene_many(32), lambda x: x.double())
+    bufs64 = tuple(b.double() for b in bufs)
+    tetra64 = O.tetra_constants(float(g["eps"]), torch.float64)
+    for mode in (0, 4):
+        with torch.no_grad():
+            img64, aux64 = O.render(spec64, bufs64, q.double(), t.double(), mode, 1, steps, float(g["eps"]),
+                                    return_aux=True, tetra=tetra64)
+            img32 = O.render(O.scene_many(32), bufs, q, t, mode, 1, steps, float(g["eps"]))
+        want64, want32 = g[f"mode{mode}_f64"], g[f"mode{mode}"]
+        ch = want32.shape[-1]
+        assert img64.dtype == torch.float64
+        close(img64[..., :ch], want64, atol=1e-9, rtol=1e-9)
+        err = np.abs(img32[..., :ch].double().numpy() - want32.astype(np.float64))
+        spread = np.abs(want32.astype(np.float64) - want64).max(axis=-1, keepdims=True)
+        assert not ((err > 1e-5) & (spread <= 1e-5)).any()
+        assert 0 < (spread > 1e-5).sum() < 0.05 * spread.size          # the ill-conditioned pixels exist and are few
+    close(aux64["p"], g["p_f64"], atol=1e-9, rtol=1e-9)
