@@ -220,7 +220,12 @@ int rm_camera_forward(const RmCamera* cam, const void* orientation /*device [N,4
  * normals/laplacian -> shader, rows [row_begin,row_end) of every camera.
  *   orientation, translation : device [N,4], [N,3], element type cam->dtype.
  *   image   : device [N,rows,W,3] of image_dtype (F32, F16; F64 for modes 6,7 with a float64 colormap).
- *   p_final : nullable fp32 [N,rows,W,3]; traj: nullable fp32 [steps,N*rows*W,3]; nexec nullable.
+ *   p_final : nullable fp32 [N,rows,W,3]; nexec nullable int32 [N,rows,W].
+ *   traj    : nullable fp32, rm_render_traj_floats(...) floats: the iterates of the march for rm_render_backward, laid
+ *             out [step][component][wave tile * 64 + lane] so that every store of a wave is 256 contiguous bytes; private
+ *             to this pair of entry points.
+ *   normal_u : nullable fp32 [N,rows,W,3]: the un-normalised normal of the final point (the normal is normal_u /
+ *             |normal_u|); handed to rm_render_backward it saves that kernel eight scene evaluations per ray.
  *   minmax  : device uint32[RM_WORK_WORDS] prepared by rm_minmax_init.  Holds the tile queues of
  *             RM_FLAG_DYNAMIC_TILES (NULL = static striding).  Words 0-2 are required for modes 1,2,5
  *             (global min/max, shader.py:35-36, 52-53, 84).
@@ -245,11 +250,14 @@ int rm_camera_forward(const RmCamera* cam, const void* orientation /*device [N,4
 int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                       const void* orientation, const void* translation,
                       void* image, int32_t image_dtype, float* first_pass, float* p_final, float* traj, int32_t* nexec,
-                      uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype,
+                      float* normal_u, uint32_t* minmax, const void* cmap, int32_t cmap_size, int32_t cmap_dtype,
                       int32_t mode, int32_t degree, int32_t steps,
                       int32_t row_begin, int32_t row_end, int32_t flags,
                       const int32_t* tile_order, int32_t* tile_cost,
                       float* park_ws, int64_t park_capacity, void* stream);
+
+/* floats of the `traj` buffer of rm_render_forward / rm_render_backward for a band of `rows` rows */
+int64_t rm_render_traj_floats(int32_t num_cameras, int32_t rows, int32_t width, int32_t steps, int32_t flags);
 
 /* floats of a parking workspace for up to `capacity` rays (4 per ray: pixel index and the iterate) */
 int64_t rm_park_floats(int64_t capacity);
@@ -322,6 +330,7 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra,
                        const float* orientation, const float* translation,
                        const float* traj, const int32_t* nexec, const float* p_final,
+                       const float* normal_u /*nullable: as written by the forward call (else recomputed)*/,
                        const float* grad_image, float* grad_params, float* partials, uint32_t* work,
                        float* grad_pos /*nullable [R,3]*/, float* grad_dirs /*nullable [R,3]*/,
                        float* grad_qdir /*nullable [R,4]: per-ray dL/d(orientation) through the shader's own use of the
@@ -339,7 +348,8 @@ int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, vo
  * every remaining step; walked by their own wave they are the critical path of the launch, so (with
  * RM_FLAG_EARLY_OUT and a `work` buffer) up to hard_capacity of them are put on a list and all their
  * (ray, step) pairs are evaluated in parallel by three follow-up kernels.  Rays beyond the capacity are walked
- * in place; hard_ws = NULL switches the path off.  Same gradients either way (to summation order). */
+ * in place; hard_ws = NULL switches the path off.  Same gradients either way (to summation order).  hard_ws must be
+ * 16-byte aligned. */
 int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps);
 
 /* VJP of PinholeCamera.forward (rendering/ray_marching.py:57-64) w.r.t. the pose: reduces per-ray

@@ -74,8 +74,9 @@ _SIGNATURES = {
     "rm_normals_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmTetra), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "rm_camera_forward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P]),
     "rm_render_forward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
-                                    _P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
+                                    _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    "rm_render_traj_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_park_floats": (C.c_int64, [C.c_int64]),
     "rm_wave_tiles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rm_tile_order_from_cost": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P]),
@@ -89,7 +90,7 @@ _SIGNATURES = {
                                    C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_shade_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_render_backward": (C.c_int, [C.POINTER(RmScene), C.POINTER(RmCamera), C.POINTER(RmTetra), _P, _P,
-                                     _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "rm_sum_rows": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),

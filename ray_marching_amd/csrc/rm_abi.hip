@@ -171,7 +171,8 @@ int64_t rm_grad_partials_floats(const RmScene* scene, int64_t n) {
 
 int64_t rm_bwd_hard_floats(int64_t capacity, int32_t steps) {
   if (capacity <= 0 || steps < 0) return 0;
-  return capacity * (2 + 8) + (int64_t)steps * capacity * 6;      // ray, step, state[8]; n[steps][cap][4], g[steps][cap], pairs[steps*cap]
+  // ray, trajectory slot, step, state[8]; n[steps][cap][4], p[steps][cap][4], g[steps][cap], pairs[steps*cap]
+  return capacity * (3 + 8) + (int64_t)steps * capacity * 10;
 }
 
 int rm_sdf_forward(const RmScene* scene, const void* points, void* dist, int64_t n, int32_t dtype, void* stream) {
@@ -302,7 +303,7 @@ int64_t rm_wave_tiles(int32_t num_cameras, int32_t rows, int32_t width, int32_t 
 
 int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const void* orientation,
                       const void* translation, void* image, int32_t image_dtype, float* first_pass, float* p_final,
-                      float* traj, int32_t* nexec, uint32_t* minmax, const void* cmap, int32_t cmap_size,
+                      float* traj, int32_t* nexec, float* normal_u, uint32_t* minmax, const void* cmap, int32_t cmap_size,
                       int32_t cmap_dtype, int32_t mode, int32_t degree, int32_t steps, int32_t row_begin,
                       int32_t row_end, int32_t flags, const int32_t* tile_order, int32_t* tile_cost,
                       float* park_ws, int64_t park_capacity, void* stream) {
@@ -322,7 +323,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
   a.orientation = orientation; a.translation = translation;
   a.image = image; a.image_dtype = image_dtype; a.first_pass = first_pass;
-  a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.minmax = minmax;
+  a.p_final = p_final; a.traj = traj; a.nexec = nexec; a.normal_u = normal_u; a.minmax = minmax;
   a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype;
   a.mode = mode; a.degree = degree; a.steps = steps; a.row_begin = row_begin; a.row_end = row_end; a.flags = flags;
   a.tile_order = tile_order; a.tile_cost = tile_cost;
@@ -341,7 +342,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
   }
   const int64_t wave_tiles = wave_tile_count(cam->num_cameras, row_end - row_begin, cam->width, flags);
   if (flags & RM_FLAG_REGEN) {
-    if (!(flags & RM_FLAG_EARLY_OUT) || !(flags & RM_FLAG_TILE8X8) || !minmax || !p_final || (steps & 3) || traj || nexec || park)
+    if (!(flags & RM_FLAG_EARLY_OUT) || !(flags & RM_FLAG_TILE8X8) || !minmax || !p_final || (steps & 3) || traj || nexec || normal_u || park)
       return fail(RM_E_BADARG, "rm_render_forward: RM_FLAG_REGEN needs EARLY_OUT, TILE8X8, minmax, p_final, steps %% 4 == 0 "
                                "and no traj / nexec / parking");
     if (wave_tiles * 64 >= ((int64_t)1 << 31)) return fail(RM_E_BADARG, "rm_render_forward: RM_FLAG_REGEN: too many rays");
@@ -395,6 +396,11 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     return launched("k_render_parked");
   }
   return RM_OK;
+}
+
+int64_t rm_render_traj_floats(int32_t num_cameras, int32_t rows, int32_t width, int32_t steps, int32_t flags) {
+  if (steps <= 0) return 0;
+  return (int64_t)steps * 3 * 64 * wave_tile_count(num_cameras, rows, width, flags);
 }
 
 int64_t rm_park_floats(int64_t capacity) {
@@ -499,7 +505,7 @@ int rm_camera_backward(const RmCamera* cam, const float* orientation, const floa
 
 int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra* tetra, const float* orientation,
                        const float* translation, const float* traj, const int32_t* nexec, const float* p_final,
-                       const float* grad_image, float* grad_params, float* partials, uint32_t* work,
+                       const float* normal_u, const float* grad_image, float* grad_params, float* partials, uint32_t* work,
                        float* grad_pos, float* grad_dirs, float* grad_qdir, const void* cmap, int32_t cmap_size,
                        int32_t cmap_dtype, int32_t mode, int32_t degree,
                        int32_t steps, int32_t row_begin, int32_t row_end, int32_t flags, int32_t* tile_cost,
@@ -520,6 +526,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
   a.orientation = orientation; a.translation = translation;
   a.traj = const_cast<float*>(traj); a.nexec = const_cast<int32_t*>(nexec); a.p_final = const_cast<float*>(p_final);
+  a.normal_u = const_cast<float*>(normal_u);
   a.grad_image = grad_image; a.partials = partials; a.minmax = work;
   a.grad_pos = grad_pos; a.grad_dirs = grad_dirs; a.grad_qdir = grad_qdir; a.tile_cost = tile_cost;
   a.cmap = cmap; a.cmap_size = cmap_size; a.cmap_dtype = cmap_dtype; a.degree = degree;
@@ -542,13 +549,19 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     if (hard_capacity > (int64_t)1 << 21 || steps >= 2048)
       return fail(RM_E_BADARG, "rm_render_backward: deferred-ray list limited to 2^21 rays and 2047 steps");
     const int64_t cap = hard_capacity;
-    a.hard_cap = (int32_t)cap;
-    a.hard_ray = reinterpret_cast<int32_t*>(hard_ws);
-    a.hard_step = reinterpret_cast<int32_t*>(hard_ws + cap);
-    a.hard_state = hard_ws + 2 * cap;
-    a.hard_n = hard_ws + 10 * cap;
-    a.hard_g = hard_ws + 10 * cap + (int64_t)steps * cap * 4;
-    a.hard_pairs = reinterpret_cast<uint32_t*>(hard_ws + 10 * cap + (int64_t)steps * cap * 5);
+    // float4 accesses of hard_n / hard_p: 16-byte alignment of the workspace is the caller's (a fresh device allocation);
+    // the arrays in front of them are kept to multiples of 4 floats by rounding the capacity down
+    a.hard_cap = (int32_t)(cap & ~(int64_t)3);
+    const int64_t c4 = a.hard_cap;
+    if (c4 < 4 || (reinterpret_cast<uintptr_t>(hard_ws) & 15)) return fail(RM_E_BADARG, "rm_render_backward: hard_ws must be 16-byte aligned, capacity >= 4");
+    a.hard_n = hard_ws;                                                   // [steps][c4][4]
+    a.hard_p = hard_ws + (int64_t)steps * c4 * 4;                        // [steps][c4][4]
+    a.hard_state = hard_ws + (int64_t)steps * c4 * 8;                    // [c4][8]
+    a.hard_g = a.hard_state + 8 * c4;                                     // [steps][c4]
+    a.hard_pairs = reinterpret_cast<uint32_t*>(a.hard_g + (int64_t)steps * c4);
+    a.hard_ray = reinterpret_cast<int32_t*>(a.hard_pairs + (int64_t)steps * c4);
+    a.hard_slot = a.hard_ray + c4;
+    a.hard_step = a.hard_slot + c4;
   }
   if (kind == 1) rm::k_render_bwd<GB, 1><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   else if (kind == 2) rm::k_render_bwd<GB, 2><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
@@ -562,7 +575,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     if (int e = pick_launch(rm::k_bwd_hard_b<GB>, *scene, true, 128, &LB)) return e;
     rm::k_bwd_hard_n<GB><<<2 * kMaxBlocksBwd, LN.block, LN.lds, (hipStream_t)stream>>>(a);   // no accumulators: 4 waves / SIMD
     if (int e = launched("k_bwd_hard_n")) return e;
-    rm::k_bwd_hard_a<<<(int)((hard_capacity + 63) / 64), 64, 0, (hipStream_t)stream>>>(a);   // one wave per block: more CUs busy
+    rm::k_bwd_hard_a<<<(int)((a.hard_cap + 63) / 64), 64, 0, (hipStream_t)stream>>>(a);   // one wave per block: more CUs busy
     if (int e = launched("k_bwd_hard_a")) return e;
     rm::RenderArgs b = a;
     b.partials = partials + (size_t)rows * (scene->n_params + scene->n_grad_derived);     // its rows follow k_render_bwd's

@@ -1153,11 +1153,13 @@ RM_DEV Tetra load_tetra(const RmTetra& t) {
 
 // SDFNormals.forward (ray_marching.py:115-125).  `centre` = scene(p) is supplied by the caller.
 template <class SceneT>
-RM_DEV void normals_from_taps(const Tetra& T, float f0, float f1, float f2, float f3, float centre, V3& n, float& lap) {
+RM_DEV void normals_from_taps(const Tetra& T, float f0, float f1, float f2, float f3, float centre, V3& n, float& lap,
+                              V3* u_out = nullptr) {
   float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
   V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
              (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
              (T.inv[6] * d1 + T.inv[7] * d2) + T.inv[8] * d3);
+  if (u_out) *u_out = u;
   float nu = norm3(u);              // F.normalize(eps=0): u / |u|, 0/0 = NaN like the reference
 #ifdef RM_FAST_MATH
   float inv = __builtin_amdgcn_rcpf(nu);
@@ -1188,10 +1190,10 @@ RM_DEV void eval_taps(const SceneT& sc, const Tetra& T, V3 p, float& f0, float& 
 }
 
 template <class SceneT>
-RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre, V3& n, float& lap) {
+RM_DEV void normals_forward(const SceneT& sc, const Tetra& T, V3 p, float centre, V3& n, float& lap, V3* u_out = nullptr) {
   float f0, f1, f2, f3;
   eval_taps(sc, T, p, f0, f1, f2, f3);
-  normals_from_taps<SceneT>(T, f0, f1, f2, f3, centre, n, lap);
+  normals_from_taps<SceneT>(T, f0, f1, f2, f3, centre, n, lap, u_out);
 }
 
 // monotone float <-> uint map for atomic min/max

@@ -229,6 +229,29 @@ RM_DEV V3 step_point(V3 p, V3 v, float f) {
 #endif
 }
 
+// Where a recorded march keeps its iterates.  kSoa = false: [step][ray][3] (rm_march_forward: any list of rays).
+// kSoa = true (the fused frame): [step][component][slot] with slot = wave tile * 64 + lane and stride = 64 * wave tiles,
+// so each of the three stores of a wave is 256 contiguous bytes -- per-pixel [ray][3] rows of an 8x8 tile are eight
+// 96-byte pieces (measured: recording forward of the config-4 shape 135 us against 117 us without recording).
+template <bool kSoa>
+RM_DEV void traj_store(float* traj, int64_t stride, int64_t idx, int i, V3 p) {
+  if constexpr (kSoa) {
+    float* q = traj + (int64_t)(3 * i) * stride + idx;
+    q[0] = p.x; q[stride] = p.y; q[2 * stride] = p.z;
+  } else {
+    store3(traj + 3 * (int64_t)i * stride, idx, p);
+  }
+}
+template <bool kSoa>
+RM_DEV V3 traj_load(const float* traj, int64_t stride, int64_t idx, int i) {
+  if constexpr (kSoa) {
+    const float* q = traj + (int64_t)(3 * i) * stride + idx;
+    return mk3(q[0], q[stride], q[2 * stride]);
+  } else {
+    return load3(traj + 3 * (int64_t)i * stride, idx);
+  }
+}
+
 struct NoPark {
   static constexpr bool kEnabled = false;
   RM_DEV bool operator()(int, V3, bool) const { return false; }
@@ -247,7 +270,7 @@ RM_DEV int park_stride(int steps) { return steps <= 128 ? 16 : ((steps + 127) / 
 // `park(step, p_next, unsettled)`: called wave-wide at a check step when 1..RM_PARK_MAX_LANES rays of the wave are
 // not yet in a proven cycle; returns (per lane) whether the ray was put on a list -- it then belongs to
 // k_render_parked and this wave neither waits for it nor stores its pixel (`parked` out).
-template <class SceneT, class ParkF = NoPark>
+template <class SceneT, class ParkF = NoPark, bool kSoa = false>
 RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* traj, int64_t traj_stride,
                 int64_t ray, bool live, int& nexec, ParkF park = ParkF(), bool* parked = nullptr) {
   if (parked) *parked = false;
@@ -271,7 +294,7 @@ RM_DEV V3 march(const SceneT& scene, V3 p, V3 v, int steps, bool early, float* t
     // here on (measured, profiles/regen_probe.py: 32-primitive 8K band 11.45 -> 10.65 ms, 1080p scene 2 208 -> 204 us)
     if (i == RM_PRIO_TILE) __builtin_amdgcn_s_setprio(3);
 #endif
-    if (traj && live) store3(traj + 3 * (int64_t)i * traj_stride, ray, p);
+    if (traj && live) traj_store<kSoa>(traj, traj_stride, ray, i, p);
     float f = scene.eval_near(p, (i & 15) ? move : __builtin_nanf(""));
     move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
     V3 pn = step_point(p, v, f);
@@ -364,7 +387,7 @@ struct NoDefer {
 
 // `defer(i, lambda, gv, active)`: called once, wave-wide, when more than RM_BWD_INLINE_STEPS non-converged steps
 // remain; returns (per lane) whether the ray was handed to the deferred-ray kernels, which then own its outputs.
-template <class SceneT, class DeferF = NoDefer>
+template <class SceneT, class DeferF = NoDefer, bool kSoa = false>
 RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
                         int64_t ray, int nexec, int steps, bool want_gv, V3& gv, bool early, int* walked = nullptr,
                         DeferF defer = DeferF(), bool* deferred_out = nullptr) {
@@ -375,13 +398,13 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
   if (walked) *walked = 0;
   if (steps <= 0) return lam;               // no trajectory buffer at all in that case
   int i = steps - 1;
-  auto iterate = [&](int k) { return (k < nexec) ? load3(traj + 3 * (int64_t)k * traj_stride, ray) : p_final; };
+  auto iterate = [&](int k) { return (k < nexec) ? traj_load<kSoa>(traj, traj_stride, ray, k) : p_final; };
   auto noise = [&](float gf) {              // |g| below the rounding-error bound of its own dot product
     return fabsf(gf) <= 2.4e-7f * ((fabsf(lam.x * v.x) + fabsf(lam.y * v.y)) + fabsf(lam.z * v.z));
   };
   auto finish_frozen = [&](int k) {         // steps 0..k skipped with lambda frozen: sum_i f(p_i) = (p_{k+1} - p_0).v / |v|^2
     if (!want_gv) return;
-    V3 dp = iterate(k + 1) - load3(traj, ray);
+    V3 dp = iterate(k + 1) - traj_load<kSoa>(traj, traj_stride, ray, 0);
     float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
     gv = gv + sumf * lam;
   };
@@ -513,15 +536,9 @@ __global__ void __launch_bounds__(256) k_normals_fwd(RmScene sc, RmTetra tetra, 
   }
 }
 
-// VJP of normals_forward.  gn: dL/dn, gl: dL/dlap.  Returns dL/dp.
+// VJP of normals_forward.  u: the un-normalised normal of the forward pass, gn: dL/dn, gl: dL/dlap.  Returns dL/dp.
 template <class SceneT>
-RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 gn, float gl, bool need_lap) {
-  float f0, f1, f2, f3;
-  eval_taps(sc, T, p, f0, f1, f2, f3);
-  float d1 = f1 - f0, d2 = f2 - f0, d3 = f3 - f0;
-  V3 u = mk3((T.inv[0] * d1 + T.inv[1] * d2) + T.inv[2] * d3,
-             (T.inv[3] * d1 + T.inv[4] * d2) + T.inv[5] * d3,
-             (T.inv[6] * d1 + T.inv[7] * d2) + T.inv[8] * d3);
+RM_DEV V3 normals_backward(const SceneT& sc, const Tetra& T, V3 p, V3 u, V3 gn, float gl, bool need_lap) {
   float nu = norm3(u);
   V3 n = mk3(u.x / nu, u.y / nu, u.z / nu);
   // n = u / |u|  ->  g_u = (g_n - n (n.g_n)) / |u|
@@ -569,7 +586,10 @@ __global__ void __launch_bounds__(256) k_normals_bwd(RmScene sc, RmTetra tetra, 
     int64_t ic = live ? i : n - 1;
     V3 g = (gn && live) ? load3(gn, ic) : mk3(0.0f, 0.0f, 0.0f);
     float gls = (gl && live) ? gl[ic] : 0.0f;
-    V3 gp = normals_backward(scene, T, load3(pts, ic), g, gls, gl != nullptr);
+    const V3 pt = load3(pts, ic);
+    V3 nn, uu; float ll;
+    normals_forward(scene, T, pt, 0.0f, nn, ll, &uu);
+    V3 gp = normals_backward(scene, T, pt, uu, g, gls, gl != nullptr);
     if (live && gpts) store3(gpts, i, gp);
   }
   flush_accumulators<Cfg>(scene, n_acc, partials, rm_smem + ((sc.n_params + sc.n_derived + 3) & ~3));
@@ -587,8 +607,10 @@ struct RenderArgs {
   void* image;               // [N,rows,W,3] of image_dtype
   float* first_pass;         // modes 1, 2, 5: fp32 [N,rows,W,3] un-normalised values
   float* p_final;            // nullable
-  float* traj;               // nullable [steps, R, 3]
+  float* traj;               // nullable [steps][3][64 * wave tiles]  (traj_store<true>: slot = tile * 64 + lane)
   int32_t* nexec;            // nullable
+  float* normal_u;           // nullable [R,3]: the un-normalised normal of the final point (training frames: the backward
+                             // kernel then needs neither the four tap evaluations of the shader VJP nor those of the normalisation VJP)
   uint32_t* minmax;          // nullable
   const void* cmap;          // nullable, [cmap_size,3] of cmap_dtype
   int32_t cmap_size, cmap_dtype, image_dtype;
@@ -607,10 +629,12 @@ struct RenderArgs {
   int32_t park_seg;          // rays per (list, shard) segment
   // deferred rays of the reverse sweep (k_bwd_hard_*), all nullable / 0
   int32_t* hard_ray;         // [cap] band-output index of the ray
+  int32_t* hard_slot;        // [cap] its trajectory slot (wave tile * 64 + lane)
   int32_t* hard_step;        // [cap] highest step index still to be walked
   float* hard_state;         // [cap][8] lambda(3), dL/dv so far(3)
   float* hard_n;             // [steps][cap][4] grad_p f(p_s) for unit upstream, f(p_s)
   float* hard_g;             // [steps][cap] upstream g_s
+  float* hard_p;             // [steps][cap][4] the iterate p_s itself (k_bwd_hard_b reads it by pair code: no ray -> nexec -> trajectory chain)
   uint32_t* hard_pairs;      // [steps * cap] (ray slot << 11 | step) of every pair with g != 0, densely packed
   int32_t hard_cap;
 };
@@ -968,9 +992,10 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   // the other six modes skip the evaluation -- a fifth of this epilogue's scene evaluations
   float dist = 0.0f;
   if (mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN) dist = scene.eval(p);
-  V3 n = mk3(0.0f, 0.0f, 0.0f);
+  V3 n = mk3(0.0f, 0.0f, 0.0f), u = n;
   float lap = 0.0f;
-  if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap);
+  if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap, &u);
+  if (a.normal_u && r.live) store3(a.normal_u, r.li, u);
   ShadeIn si;
   si.o = r.o; si.v = r.v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
   si.qw = r.ps.w; si.qv = r.ps.qv;
@@ -1033,8 +1058,6 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store);
   Tetra T = load_tetra(a.tetra);
-  const int rows = a.row_end - a.row_begin;
-  const int64_t R = (int64_t)a.cam.num_cameras * rows * a.cam.width;
   const bool early = a.flags & RM_FLAG_EARLY_OUT;
   MinMaxAcc mm{__builtin_inff(), -__builtin_inff(), false};
   const int64_t ntiles = wave_tiles(a);
@@ -1044,7 +1067,10 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     TileRays r = load_tile_rays(a, tile);
     int nexec;
     bool parked;
-    V3 p = march(scene, r.o, r.v, a.steps, early, a.traj, R, r.li, r.live, nexec, ParkToList{a, r.li}, &parked);
+    // (a recorded trajectory is indexed by the wave tile's slot, not by the pixel: traj_store<true>)
+    V3 p = march<decltype(scene), ParkToList, true>(scene, r.o, r.v, a.steps, early, a.traj, ntiles * 64,
+                                                    a.traj ? tile * 64 + (threadIdx.x & 63) : r.li, r.live, nexec,
+                                                    ParkToList{a, r.li}, &parked);
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tile] = nexec;     // nexec is wave-uniform
     r.live = r.live && !parked;                 // a parked ray's pixel is written by k_render_parked
     finish_tile(a, scene, T, r, p, nexec, mm);
@@ -1609,7 +1635,7 @@ __global__ void k_camera_bwd_finish(const float* __restrict__ partials, int bloc
 // appends the active lanes of a wave to the deferred-ray list (one returning atomic per wave)
 struct DeferToList {
   const RenderArgs& a;
-  int64_t li;
+  int64_t li, tslot;
   RM_DEV bool operator()(int i, V3 lam, V3 gv, bool active) const {
     if (a.hard_cap <= 0 || !a.minmax) return false;
     const int lane = threadIdx.x & 63;
@@ -1621,6 +1647,7 @@ struct DeferToList {
     const bool ok = active && slot < (uint32_t)a.hard_cap;       // list full: the wave walks these rays itself
     if (ok) {
       a.hard_ray[slot] = (int32_t)li;
+      a.hard_slot[slot] = (int32_t)tslot;
       a.hard_step[slot] = i;
       float* st = a.hard_state + 8 * (int64_t)slot;
       st[0] = lam.x; st[1] = lam.y; st[2] = lam.z; st[3] = gv.x; st[4] = gv.y; st[5] = gv.z;
@@ -1646,7 +1673,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
   zero_accumulators<Cfg>(scene, n_acc);
   Tetra T = load_tetra(a.tetra);
   const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
-  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
   const int64_t ntiles = wave_tiles(a);
   for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
     int cam, row, col;
@@ -1658,10 +1684,17 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
     V3 v = qrot(load3(static_cast<const float*>(a.cam.ray_directions), gi), ps.w, ps.qv);
     V3 p = load3(a.p_final, li);
     V3 gi3 = live ? load3(a.grad_image, li) : mk3(0.0f, 0.0f, 0.0f);
-    // recompute the normal for the shader VJP
-    float c0 = 0.0f;
-    V3 n; float lap;
-    normals_forward(scene, T, p, c0, n, lap);
+    // the normal for the shader VJP: from the un-normalised normal the recording forward left (same division, same
+    // bits), or -- callers without that buffer -- from four tap evaluations
+    V3 n, u = mk3(0.0f, 0.0f, 0.0f);
+    if (a.normal_u) {
+      u = load3(a.normal_u, li);
+      const float nu = norm3(u);
+      n = mk3(u.x / nu, u.y / nu, u.z / nu);
+    } else {
+      float lap;
+      normals_forward(scene, T, p, 0.0f, n, lap, &u);
+    }
     V3 gn = mk3(0.0f, 0.0f, 0.0f);
     V3 gv = mk3(0.0f, 0.0f, 0.0f);
     float gq0 = 0.0f, gq1 = 0.0f, gq2 = 0.0f, gq3 = 0.0f;     // direct dependence of the shader on the pose quaternion
@@ -1763,11 +1796,13 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
       } else if constexpr (kKind == 3) {
         lam = neg(gp_direct);
       } else {
-        lam = normals_backward(scene, T, p, gn, kKind == 1 ? gi3.x : 0.0f, kKind == 1);
+        lam = normals_backward(scene, T, p, u, gn, kKind == 1 ? gi3.x : 0.0f, kKind == 1);
       }
       int ne = a.nexec ? a.nexec[li] : a.steps;
-      lam = march_reverse(scene, lam, v, p, a.traj, R, li, ne, a.steps, a.grad_dirs != nullptr, gv,
-                          a.flags & RM_FLAG_EARLY_OUT, &walked, DeferToList{a, li}, &deferred);
+      const int64_t tslot = tc.tile * 64 + (threadIdx.x & 63);
+      lam = march_reverse<decltype(scene), DeferToList, true>(scene, lam, v, p, a.traj, ntiles * 64, tslot, ne, a.steps,
+                                                              a.grad_dirs != nullptr, gv, a.flags & RM_FLAG_EARLY_OUT, &walked,
+                                                              DeferToList{a, li, tslot}, &deferred);
     }
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
     if constexpr (kKind == 3) {
@@ -1795,7 +1830,8 @@ RM_DEV int hard_count(const RenderArgs& a) {
 struct HardItem {
   int s, h;
   bool need;      // this lane has a ray and the step is one of its remaining ones
-  int64_t ray;
+  int64_t ray;    // band-output index
+  int64_t slot;   // trajectory slot
 };
 RM_DEV HardItem hard_item(const RenderArgs& a, int64_t item, int groups, int H) {
   HardItem it;
@@ -1804,11 +1840,12 @@ RM_DEV HardItem hard_item(const RenderArgs& a, int64_t item, int groups, int H) 
   const int hc = it.h < H ? it.h : H - 1;
   it.need = it.h < H && it.s <= a.hard_step[hc];
   it.ray = a.hard_ray[hc];
+  it.slot = a.hard_slot[hc];
   return it;
 }
-RM_DEV V3 hard_point(const RenderArgs& a, int64_t R, int s, int64_t ray) {
+RM_DEV V3 hard_point(const RenderArgs& a, int64_t R64, int s, int64_t ray, int64_t slot) {
   const int ne = a.nexec ? a.nexec[ray] : a.steps;
-  return (s < ne) ? load3(a.traj + 3 * (int64_t)s * R, ray) : load3(a.p_final, ray);
+  return (s < ne) ? traj_load<true>(a.traj, R64, slot, s) : load3(a.p_final, ray);
 }
 
 template <class Cfg>
@@ -1817,26 +1854,28 @@ __global__ void __launch_bounds__(256) k_bwd_hard_n(RenderArgs a) {
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int H = hard_count(a);
   if (H == 0) return;
-  const int64_t R = (int64_t)a.cam.num_cameras * (a.row_end - a.row_begin) * a.cam.width;
+  const int64_t R = 64 * wave_tiles(a);
   const int groups = (H + 63) >> 6;
   const int64_t items = (int64_t)groups * a.steps;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   // the next item's list entry and trajectory point (two dependent, scattered loads) are fetched before the
   // current item's VJP, so their latency hides behind ~600 instructions
   const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  HardItem cur{0, 0, false, 0};
+  HardItem cur{0, 0, false, 0, 0};
   V3 pc = mk3(0.0f, 0.0f, 0.0f);
-  if (first < items) { cur = hard_item(a, first, groups, H); pc = hard_point(a, R, cur.s, cur.ray); }
+  if (first < items) { cur = hard_item(a, first, groups, H); pc = hard_point(a, R, cur.s, cur.ray, cur.slot); }
   for (int64_t item = first; item < items; item += nwaves) {
-    HardItem nxt{0, 0, false, 0};
+    HardItem nxt{0, 0, false, 0, 0};
     V3 pn = mk3(0.0f, 0.0f, 0.0f);
-    if (item + nwaves < items) { nxt = hard_item(a, item + nwaves, groups, H); pn = hard_point(a, R, nxt.s, nxt.ray); }
+    if (item + nwaves < items) { nxt = hard_item(a, item + nwaves, groups, H); pn = hard_point(a, R, nxt.s, nxt.ray, nxt.slot); }
     if (__any(cur.need)) {
       float f;
       const V3 n = scene.vjp_point(pc, 1.0f, &f);
       if (cur.need) {
-        float* dst = a.hard_n + 4 * ((int64_t)cur.s * a.hard_cap + cur.h);
-        dst[0] = n.x; dst[1] = n.y; dst[2] = n.z; dst[3] = f;
+        const int64_t at = 4 * ((int64_t)cur.s * a.hard_cap + cur.h);
+        *reinterpret_cast<float4*>(a.hard_n + at) = make_float4(n.x, n.y, n.z, f);
+        // the point itself, next to its gradient: k_bwd_hard_a copies it into the pair records k_bwd_hard_b works from
+        *reinterpret_cast<float4*>(a.hard_p + at) = make_float4(pc.x, pc.y, pc.z, 0.0f);
       }
     }
     cur = nxt; pc = pn;
@@ -1850,8 +1889,8 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
   const bool valid = h0 < H;
   const int h = valid ? h0 : H - 1;
   const int W = a.cam.width, Hh = a.cam.height, rows = a.row_end - a.row_begin;
-  const int64_t R = (int64_t)a.cam.num_cameras * rows * W;
-  const int64_t li = a.hard_ray[h];
+  const int64_t R = 64 * wave_tiles(a);
+  const int64_t li = a.hard_ray[h], tslot = a.hard_slot[h];
   const int cam = (int)(li / ((int64_t)rows * W));
   const int64_t rem = li - (int64_t)cam * rows * W;
   const int row = (int)(rem / W), col = (int)(rem - (int64_t)row * W);
@@ -1900,7 +1939,7 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
       a.hard_pairs[base + k] = ((uint32_t)h << RM_HARD_STEP_BITS) | (uint32_t)(top - (int)k);
   }
   if (want_gv && s >= 0) {     // steps 0..s with lambda frozen: sum_i f(p_i) = (p_{s+1} - p_0).v / |v|^2
-    const V3 dp = hard_point(a, R, s + 1, li) - load3(a.traj, li);
+    const V3 dp = hard_point(a, R, s + 1, li, tslot) - traj_load<true>(a.traj, R, tslot, 0);
     const float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
     gv = gv + sumf * lam;
   }
@@ -1915,9 +1954,10 @@ __global__ void __launch_bounds__(256) k_bwd_hard_b(RenderArgs a) {
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(a.scene);
   zero_accumulators<Cfg>(scene, n_acc);
-  const int64_t R = (int64_t)a.cam.num_cameras * (a.row_end - a.row_begin) * a.cam.width;
   // the (ray, step) pairs with a non-zero upstream, listed densely by k_bwd_hard_a: 64 of them per wave item,
-  // whatever ray and step they belong to (config 4: 10.8 k items instead of 17.6 k for ray-aligned items)
+  // whatever ray and step they belong to (config 4: 10.8 k items instead of 17.6 k for ray-aligned items).  A pair's
+  // upstream and point are both addressed by its code alone (k_bwd_hard_n left the point next to its gradient):
+  // one level of indirection instead of code -> ray -> nexec -> trajectory
   const int64_t npairs = a.minmax[RM_WORK_HARD_PAIRS];
   const int64_t items = (npairs + 63) >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -1928,8 +1968,10 @@ __global__ void __launch_bounds__(256) k_bwd_hard_b(RenderArgs a) {
     if (item >= items) return;
     const uint32_t code = a.hard_pairs[k < npairs ? k : npairs - 1];
     const int h = (int)(code >> RM_HARD_STEP_BITS), st = (int)(code & ((1u << RM_HARD_STEP_BITS) - 1u));
-    g = (k < npairs) ? a.hard_g[(int64_t)st * a.hard_cap + h] : 0.0f;
-    p = hard_point(a, R, st, a.hard_ray[h]);
+    const int64_t at = (int64_t)st * a.hard_cap + h;
+    const float4 pt = *reinterpret_cast<const float4*>(a.hard_p + 4 * at);
+    g = (k < npairs) ? a.hard_g[at] : 0.0f;
+    p = mk3(pt.x, pt.y, pt.z);
   };
   float gc; V3 pc;
   fetch(first, gc, pc);

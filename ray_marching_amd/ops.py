@@ -450,8 +450,11 @@ class Render(torch.autograd.Function):
             flags &= ~(_abi.FLAG_REGEN | _abi.FLAG_ORDER_PER_RAY)
         # training: saved for the reverse sweep; ray regeneration: where the march kernel leaves the final iterates
         p_final = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if (record or regen) else None
-        traj = torch.empty((steps, R, 3), dtype=torch.float32, device=dev) if (record and steps > 0) else None
+        # the trajectory (layout private to rm_render_forward / rm_render_backward) and the un-normalised normals
+        traj = torch.empty(int(_lib.rm_render_traj_floats(n, nrows, w, steps, flags)), dtype=torch.float32, device=dev) \
+            if (record and steps > 0) else None
         nexec = torch.empty(R, dtype=torch.int32, device=dev) if record else None
+        normal_u = torch.empty((n, nrows, w, 3), dtype=torch.float32, device=dev) if record else None
         # parking workspace (rays that never settle are finished by a dense second kernel): room for 2 R rays
         # over the 32 list segments; inference frames of >= 48 steps with the early-out only
         park_cap = 0
@@ -470,7 +473,7 @@ class Render(torch.autograd.Function):
             lib = cs.lib(False, precision)
             _abi.check(lib.rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
                                              _abi.dtype_code(image_dtype), _abi.ptr(first_pass),
-                                             _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(minmax),
+                                             _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(normal_u), _abi.ptr(minmax),
                                              _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                              0 if cmap is None else _abi.dtype_code(cmap.dtype),
                                              mode, degree, steps, r0, r1, flags, _abi.ptr(tile_order), _abi.ptr(tile_cost),
@@ -497,7 +500,7 @@ class Render(torch.autograd.Function):
         if record:
             # the leaves are saved too: autograd then refuses a backward after an in-place edit of a parameter
             # (the backward kernels read the live storages, which must still hold the forward's values)
-            ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, *leaves)
+            ctx.save_for_backward(prm, q, t, rp, rd, p_final, traj, nexec, normal_u, *leaves)
             # Laplacian shader: the un-normalised values and their largest magnitude, for the normalisation's VJP
             ctx.lap = (first_pass, lohi, allreduce_minmax is not None) if mode in _GLOBAL_MODES else None
             ctx.scene_keep = keep       # (program, packed block or None, pointer table or None): what backward reads through
@@ -511,7 +514,7 @@ class Render(torch.autograd.Function):
             # the frame itself rendered (like the reference, which renders every mode with grad enabled);
             # only differentiating through a shader without a fused VJP is refused
             raise NotImplementedError(f"fused backward exists for shader modes {sorted(_FUSED_VJP_MODES)}, not {ctx.mode}")
-        prm, q, t, rp, rd, p_final, traj, nexec, *leaves = ctx.saved_tensors
+        prm, q, t, rp, rd, p_final, traj, nexec, normal_u, *leaves = ctx.saved_tensors
         cs, dev = ctx.cs, rp.device
         g = _f32c(grad_image)
         if ctx.mode in _GLOBAL_MODES:
@@ -546,7 +549,7 @@ class Render(torch.autograd.Function):
             if bwd_tile_cost_sink is not None:             # measurement runs: word 32 of `work` = rays deferred
                 globals()["bwd_last_work"], globals()["bwd_last_hard"] = work, (hard, hard_cap)
             _abi.check(lib.rm_render_backward(s, cam, ctx.tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(traj),
-                                               _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(g), _abi.ptr(gprm),
+                                               _abi.ptr(nexec), _abi.ptr(p_final), _abi.ptr(normal_u), _abi.ptr(g), _abi.ptr(gprm),
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
                                                _abi.ptr(gqdir), _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                                0 if cmap is None else _abi.dtype_code(cmap.dtype),

@@ -100,7 +100,7 @@ def test_regen_flag_is_refused_without_its_buffers():
     work = torch.empty(_abi.WORK_WORDS, dtype=torch.int32, device=DEV)
     flags = ops.default_flags(True, True, True, True)
     rc = _abi.lib.rm_render_forward(s, cam, loop.normals.tetra(), _abi.ptr(q), _abi.ptr(t), _abi.ptr(image), _abi.dtype_code(torch.float32),
-                                    None, None, None, None, _abi.ptr(work), None, 0, 0, 4, 1, 32, 0, 64, flags, None, None, None, 0,
+                                    None, None, None, None, None, _abi.ptr(work), None, 0, 0, 4, 1, 32, 0, 64, flags, None, None, None, 0,
                                     _abi.current_stream(rp.device))
     assert rc == -1 and b"RM_FLAG_REGEN" in _abi.lib.rm_last_error()
     torch.cuda.synchronize()

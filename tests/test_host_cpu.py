@@ -59,7 +59,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     tet = _abi.RmTetra()
 
     def render(mode, r0=0, r1=4, image_dtype=0, cam_=cam, cmap=None, cmap_dtype=0):
-        return lib.rm_render_forward(ok, cam_, tet, 16, 16, 16, image_dtype, None, None, None, None, None, cmap,
+        return lib.rm_render_forward(ok, cam_, tet, 16, 16, 16, image_dtype, None, None, None, None, None, None, cmap,
                                      0 if cmap is None else 8, cmap_dtype, mode, 1, 8, r0, r1, 0, None, None, None, 0, None)
 
     assert render(9) == -1 and b"mode" in lib.rm_last_error()
@@ -70,7 +70,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert render(6, cmap=16, cmap_dtype=7) == -1
 
     def regen(steps=8, p_final=16, minmax=16, flags=1 | 2 | 4 | 8, traj=None):
-        return lib.rm_render_forward(ok, cam, tet, 16, 16, 16, 0, None, p_final, traj, None, minmax, None, 0, 0, 0, 1, steps,
+        return lib.rm_render_forward(ok, cam, tet, 16, 16, 16, 0, None, p_final, traj, None, None, minmax, None, 0, 0, 0, 1, steps,
                                      0, 4, flags, None, None, None, 0, None)
 
     # ray regeneration states its requirements instead of doing something else
@@ -84,6 +84,7 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert render(0, cam_=cam64) == -1 and b"camera dtype" in lib.rm_last_error()
     assert lib.rm_wave_tiles(1, 1080, 1920, _abi.FLAG_TILE8X8) == 135 * 240
     assert lib.rm_wave_tiles(2, 9, 65, 0) == (2 * 9 * 65 + 63) // 64
+    assert lib.rm_render_traj_floats(1, 9, 65, 5, _abi.FLAG_TILE8X8) == 5 * 3 * 64 * (2 * 9) and lib.rm_render_traj_floats(1, 9, 65, 0, 0) == 0
 
 
 def _validate(rows, n_params, n_derived, stack, slots):
