@@ -292,6 +292,25 @@ def backward_probe(dev):
         torch.cuda.synchronize()
         walls.append((time.perf_counter() - t0) / n * 1e3)
     wall = sorted(walls)[len(walls) // 2]
+    # (3) the same loop through RenderLoop.training_step: forward + loss + backward captured into one HIP graph on first
+    # use, replayed per iteration (pose copied into static buffers): the training loop off the host
+    helper_ms = None
+    if not any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")):
+        for p in scene.parameters():
+            p.grad = None
+        stepper = loop.training_step(lambda image: (image[..., :1] - target).pow(2).mean(), mode=0, marching_steps=64)
+        for _ in range(5):
+            stepper(q, t)
+        runs = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                stepper(q, t)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0) / n * 1e3)
+        helper_ms = sorted(runs)[len(runs) // 2]
+        del stepper
     rays, S = h * w, 64
     n_bytes = step_bytes(rays, S)
     traffic, why = backward_traffic_record(h)
@@ -299,11 +318,13 @@ def backward_probe(dev):
         log(f"fwd_bwd.roofline.traffic: {why}")
     out = {"config": "closed make_test_scene 512x512x64, lambertian MSE, 40 parameters",
            "fwd_bwd_ms": wall,
-           "note": "fwd_bwd_ms = wall time per step of a 100-step eager loop with no synchronisation inside; *_sync_ms = "
+           "training_step_ms": helper_ms,
+           "note": "fwd_bwd_ms = wall time per step of a 100-step eager loop with no synchronisation inside; training_step_ms = "
+                   "the same loop through RenderLoop.training_step (one HIP graph per iteration, captured on first use); *_sync_ms = "
                    "one step issued into an idle GPU and waited for, split by events; graph_fwd_bwd_ms = the same "
                    "step replayed from a HIP graph.  Kernels of a step: k_render_fwd (recording), k_render_bwd, "
                    "k_bwd_hard_n/_a/_b (rays whose march did not settle, evaluated per (ray, step) in parallel), "
-                   "reductions; per-kernel times in profiles/r02_bwd_kernel_stats.csv",
+                   "reductions; per-kernel times in profiles/r03_bwd_kernel_stats_512.csv",
            "fwd_bwd_ms_runs": walls,
            "fwd_sync_ms": sync_fwd, "bwd_sync_ms": sync_bwd, "fwd_bwd_sync_ms": sync_fwd + sync_bwd,
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,

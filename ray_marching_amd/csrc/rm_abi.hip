@@ -30,8 +30,8 @@ int fail(int code, const char* fmt, ...) {
 }
 
 constexpr int kMaxBlocks = 2048;        // persistent grid cap: 256 CUs x 8 blocks
-constexpr int kMaxBlocksBwd = 1024;     // rows of per-block partial sums a backward kernel may write
-constexpr int kHardBlocksB = 1024;      // + rows of k_bwd_hard_b (deferred rays)
+constexpr int kMaxBlocksBwd = 2048;     // rows of per-block partial sums a backward kernel may write
+constexpr int kHardBlocksB = 2048;      // + rows of k_bwd_hard_b (deferred rays)
 constexpr int kPartialRows = kMaxBlocksBwd + kHardBlocksB;
 constexpr size_t kLdsDefault = 64 * 1024;
 constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
@@ -135,6 +135,10 @@ int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
 // frame kernel: 1280 blocks x 4 waves = 5 waves/SIMD measured best with the atomic tile queues
 // (profiles/grid_sweep.py: 512 -> 463 us, 1024 -> 376, 1280 -> 371, 2048 -> 390)
 int tune_max_blocks() { static int v = env_int("RM_MAX_BLOCKS", 1280); return v; }
+// backward kernels: blocks of 128 threads; 1024 = 2 waves per SIMD (what 250-VGPR kernels can hold)
+int tune_bwd_blocks() { static int v = env_int("RM_BWD_BLOCKS", 1024); return v < 1 ? 1 : (v > kMaxBlocksBwd ? kMaxBlocksBwd : v); }
+int tune_hardb_blocks() { static int v = env_int("RM_HARDB_BLOCKS", 1024); return v < 1 ? 1 : (v > kHardBlocksB ? kHardBlocksB : v); }
+int tune_hardn_blocks() { static int v = env_int("RM_HARDN_BLOCKS", 2048); return v < 1 ? 1 : v; }
 
 int launched(const char* what) {
   hipError_t e = hipGetLastError();
@@ -196,7 +200,7 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
   if (n <= 0 || !points || !grad_dist || !partials) return fail(RM_E_BADARG, "rm_sdf_backward: null buffer / n<=0");
   Launch L;
   if (int e = pick_launch(rm::k_sdf_bwd<GB>, *scene, true, 128, &L)) return e;
-  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  int grid = grid_for((n + L.block - 1) / L.block, 1024);
   rm::k_sdf_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
   if (int e = launched("k_sdf_bwd")) return e;
   return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
@@ -227,7 +231,7 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
     return fail(RM_E_BADARG, "rm_march_backward: bad args");
   Launch L;
   if (int e = pick_launch(rm::k_march_bwd<GB>, *scene, true, 128, &L)) return e;
-  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  int grid = grid_for((n + L.block - 1) / L.block, 1024);
   rm::k_march_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, dirs, traj, nexec, grad_out, grad_pos, grad_dirs,
                                                                    partials, n, steps);
   if (int e = launched("k_march_bwd")) return e;
@@ -258,7 +262,7 @@ int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float*
   if (!tetra || n <= 0 || !coords || !partials) return fail(RM_E_BADARG, "rm_normals_backward: bad args");
   Launch L;
   if (int e = pick_launch(rm::k_normals_bwd<GB>, *scene, true, 128, &L)) return e;
-  int grid = grid_for((n + L.block - 1) / L.block, kMaxBlocksBwd);
+  int grid = grid_for((n + L.block - 1) / L.block, 1024);
   rm::k_normals_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, grad_normals, grad_lap,
                                                                      grad_coords, partials, n);
   if (int e = launched("k_normals_bwd")) return e;
@@ -542,7 +546,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     wave_tiles = (flags & RM_FLAG_TILE8X8) ? (int64_t)cam->num_cameras * ((W + 7) >> 3) * ((rows + 7) >> 3)
                                            : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
-  int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), kMaxBlocksBwd);
+  int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), tune_bwd_blocks());
   // deferred rays: only with the reverse early exit, a workspace for the list and its counter
   const bool defer = hard_ws && hard_capacity > 0 && work && (flags & RM_FLAG_EARLY_OUT) && steps > 0;
   if (defer) {
@@ -573,15 +577,15 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     Launch LN, LB;
     if (int e = pick_launch(rm::k_bwd_hard_n<GB>, *scene, true, 128, &LN)) return e;
     if (int e = pick_launch(rm::k_bwd_hard_b<GB>, *scene, true, 128, &LB)) return e;
-    rm::k_bwd_hard_n<GB><<<2 * kMaxBlocksBwd, LN.block, LN.lds, (hipStream_t)stream>>>(a);   // no accumulators: 4 waves / SIMD
+    rm::k_bwd_hard_n<GB><<<tune_hardn_blocks(), LN.block, LN.lds, (hipStream_t)stream>>>(a);   // no accumulators: 4 waves / SIMD
     if (int e = launched("k_bwd_hard_n")) return e;
     rm::k_bwd_hard_a<<<(int)((a.hard_cap + 63) / 64), 64, 0, (hipStream_t)stream>>>(a);   // one wave per block: more CUs busy
     if (int e = launched("k_bwd_hard_a")) return e;
     rm::RenderArgs b = a;
     b.partials = partials + (size_t)rows * (scene->n_params + scene->n_grad_derived);     // its rows follow k_render_bwd's
-    rm::k_bwd_hard_b<GB><<<kHardBlocksB, LB.block, LB.lds, (hipStream_t)stream>>>(b);
+    rm::k_bwd_hard_b<GB><<<tune_hardb_blocks(), LB.block, LB.lds, (hipStream_t)stream>>>(b);
     if (int e = launched("k_bwd_hard_b")) return e;
-    rows += kHardBlocksB;
+    rows += tune_hardb_blocks();
   }
   return reduce_partials(*scene, partials, rows, grad_params, (hipStream_t)stream);
 #endif

@@ -100,6 +100,18 @@ struct StaticCfg {
 
 extern __shared__ __attribute__((aligned(16))) float rm_smem[];
 
+// occupancy targets of the register-heavy backward kernels (A/B knobs; unset = the compiler's own choice)
+#ifdef RM_BWD_WAVES_PER_EU
+#define RM_BWD_OCC __attribute__((amdgpu_waves_per_eu(RM_BWD_WAVES_PER_EU, RM_BWD_WAVES_PER_EU)))
+#else
+#define RM_BWD_OCC
+#endif
+#ifdef RM_HARDB_WAVES_PER_EU
+#define RM_HARDB_OCC __attribute__((amdgpu_waves_per_eu(RM_HARDB_WAVES_PER_EU, RM_HARDB_WAVES_PER_EU)))
+#else
+#define RM_HARDB_OCC
+#endif
+
 // ---------------------------------------------------------------------------
 // gradient accumulators: zero at start, block-reduce into partials at the end
 // ---------------------------------------------------------------------------
@@ -1666,7 +1678,7 @@ struct DeferToList {
 // Separate instantiations: kinds 1 and 2 add an inlined scene VJP, and kind 3 inside kind 0 cost the training step's
 // backward kernel 43 % (116 -> 166 us: registers across the reverse march) -- the per-pixel modes carry none of it.
 template <class Cfg, int kKind = 0>
-__global__ void __launch_bounds__(256) k_render_bwd(RenderArgs a) {
+__global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(a.scene);
@@ -1949,7 +1961,7 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(256) k_bwd_hard_b(RenderArgs a) {
+__global__ void __launch_bounds__(256) RM_HARDB_OCC k_bwd_hard_b(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int n_acc = Cfg::n_acc(a.scene);

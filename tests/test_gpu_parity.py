@@ -878,21 +878,23 @@ def test_training_step_captured_in_a_graph_matches_eager():
     import warnings
     from ray_marching_amd.graphs import capture_step
     with warnings.catch_warnings():
-        # warm-up and capture on one stream (graphs.py): torch must no longer see AccumulateGrad nodes that belong
-        # to another stream -- the cause of the aborted captures of round 1
+        # For the WHOLE body, the eager steps after the capture included: warm-up and capture run on one stream
+        # (graphs.py), and the captured result comes back detached, so no AccumulateGrad node of the capture's side
+        # stream survives to meet a later eager backward -- torch must not warn anywhere here.
         warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
         graph, loss, captured = capture_step(step, params, warmup=2)
-    for trial in range(2):
-        graph.replay()
-        torch.cuda.synchronize()
-        got_loss, got = loss.item(), [g.clone() for g in captured]
-        want_loss, want = eager()
-        assert abs(got_loss - want_loss) <= 1e-6
-        for a, b in zip(got, want):
-            assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
-        with torch.no_grad():                       # move the scene; the graph reads the live parameters
-            for p in params:
-                p.add_(0.01 * torch.randn_like(p))
+        assert loss.grad_fn is None
+        for trial in range(2):
+            graph.replay()
+            torch.cuda.synchronize()
+            got_loss, got = loss.item(), [g.clone() for g in captured]
+            want_loss, want = eager()
+            assert abs(got_loss - want_loss) <= 1e-6
+            for a, b in zip(got, want):
+                assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+            with torch.no_grad():                       # move the scene; the graph reads the live parameters
+                for p in params:
+                    p.add_(0.01 * torch.randn_like(p))
 
 
 def test_fast_precision_is_within_tolerance_of_the_reference():
