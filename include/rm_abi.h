@@ -341,6 +341,17 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                        float* hard_ws /*nullable: rm_bwd_hard_floats(hard_capacity, steps) floats*/,
                        int64_t hard_capacity, void* stream);
 
+/* VJP of the normalisation of the globally normalised shaders (modes 1 distance, 2 proximity: ((x - min) / (max - min))^(1/2.33),
+ * shader.py:33-38, 51-55; mode 5 laplacian: clamp((x / max|x| * -1 + 1) / 2, 0, 1)^(1/2.33), shader.py:81-89), in the order
+ * autograd walks it -- including the infinities and NaNs the reference's gradient carries at the rays of the frame's
+ * minimum / maximum.  raw: the un-normalised values rm_render_forward left in `first_pass` ([n,3], channel 0 is read);
+ * lohi: device {min, max} (rm_minmax_decode); grad_image: dL/d(image) [n,3]; grad_raw [n,3] out: channel 0 =
+ * dL/d(un-normalised value), channels 1, 2 = 0 -- the `grad_image` rm_render_backward expects for these modes.
+ * partials: RM_NORM_BWD_BLOCKS * 4 floats.  Two launches (block sums, then the elementwise combination); deterministic. */
+#define RM_NORM_BWD_BLOCKS 1024
+int rm_shade_norm_backward(const float* raw, const float* grad_image, const float* lohi /*device [2]*/, int32_t mode,
+                           float* grad_raw, float* partials, int64_t n_pixels, void* stream);
+
 /* out[width] = sum over n_rows rows of rows[n_rows][width], fixed summation tree (deterministic). */
 int rm_sum_rows(const float* rows, int64_t n_rows, int32_t width, float* out, void* stream);
 

@@ -38,6 +38,7 @@ def dtype_code(dtype) -> int:
     return _DTYPES[dtype]
 WORK_WORDS = 64 + 64 * 32 + 8 * 4 * 32 + 64 * 32   # RM_WORK_WORDS (min/max words, tile queues, parking counters, min/max slots)
 CAMERA_BWD_BLOCKS = 256     # RM_CAMERA_BWD_BLOCKS
+NORM_BWD_BLOCKS = 1024      # RM_NORM_BWD_BLOCKS
 MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian", "tangent", "spin")
 
 
@@ -94,6 +95,7 @@ _SIGNATURES = {
                                      _P, _P, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "rm_sum_rows": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
+    "rm_shade_norm_backward": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     "rm_bwd_hard_floats": (C.c_int64, [C.c_int64, C.c_int32]),
     "rm_camera_backward": (C.c_int, [C.POINTER(RmCamera), _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
 }

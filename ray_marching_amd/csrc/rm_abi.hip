@@ -490,6 +490,21 @@ int rm_shade_backward(const float* dirs, const float* normals, const float* fram
   return launched("k_shade_bwd");
 }
 
+int rm_shade_norm_backward(const float* raw, const float* grad_image, const float* lohi, int32_t mode, float* grad_raw,
+                           float* partials, int64_t n_pixels, void* stream) {
+  if (mode != RM_MODE_DISTANCE && mode != RM_MODE_PROXIMITY && mode != RM_MODE_LAPLACIAN)
+    return fail(RM_E_BADARG, "rm_shade_norm_backward: mode %d is not one of the globally normalised shaders (1, 2, 5)", mode);
+  if (n_pixels < 0 || (n_pixels > 0 && (!raw || !grad_image || !lohi || !grad_raw || !partials)))
+    return fail(RM_E_BADARG, "rm_shade_norm_backward: null buffer");
+  if (n_pixels == 0) return RM_OK;
+  const int blocks = grid_for((n_pixels + 255) / 256, RM_NORM_BWD_BLOCKS);
+  rm::k_shade_norm_bwd_a<<<blocks, 256, 0, (hipStream_t)stream>>>(raw, grad_image, lohi, mode, grad_raw, partials, n_pixels);
+  if (int e = launched("k_shade_norm_bwd_a")) return e;
+  rm::k_shade_norm_bwd_b<<<grid_for((n_pixels + 255) / 256, kMaxBlocks), 256, 0, (hipStream_t)stream>>>(raw, lohi, mode, grad_raw, partials,
+                                                                                                     blocks, n_pixels);
+  return launched("k_shade_norm_bwd_b");
+}
+
 int rm_camera_backward(const RmCamera* cam, const float* orientation, const float* grad_pos, const float* grad_dirs,
                        float* grad_orientation, float* grad_translation, float* partials, int32_t row_begin,
                        int32_t row_end, void* stream) {

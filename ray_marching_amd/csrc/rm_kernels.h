@@ -1503,6 +1503,103 @@ __global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n,
   }
 }
 
+// ---- VJP of the globally normalised shaders' normalisation (shader.py:33-38, 51-55, 81-89) ------------------------------
+// The normalisation is a reduction over every pixel; its VJP, in the order autograd walks it, needs two sums and two
+// counts over the frame:
+//   distance / proximity:  y = ((x - lo) / (hi - lo))^gamma with lo = min x, hi = max x (both x.min() nodes of the reference):
+//       gx = gy gamma (a / r)^(gamma - 1),  ga = gx / r,  g_r = sum(-gx a / r^2),  g_lo = -sum(ga) - g_r,
+//       dL/dx = ga + [x == hi] g_r / #[x == hi] + [x == lo] g_lo / #[x == lo]                 (a = x - lo, r = hi - lo)
+//   laplacian:  y = clamp((x / hi * -1 + 1) / 2, 0, 1)^gamma with hi = max |x|:
+//       gu = gy gamma clamp(u)^(gamma - 1) [0 <= u <= 1],  ga = gu / 2 * -1,  g_hi = sum(ga * (-x / hi^2)),
+//       dL/dx = ga / hi + [|x| == hi] (g_hi / #[|x| == hi]) sign(x)
+// x^(gamma - 1) is infinite at x = 0: the inf - inf and inf * 0 the reference's gradient carries at the rays of the
+// minimum / maximum are reproduced by doing the same IEEE operations (products with masks are products, not selects).
+// Pass A: per-pixel terms, ga into out[..., 0], block sums of the four quantities in a fixed order -> partials[block][4].
+// Pass B: every block adds the partials up in block order (deterministic), then the elementwise combination.
+struct NormBwdTerms {
+  float ga, t1;
+  bool top, bottom;
+};
+RM_DEV NormBwdTerms norm_bwd_terms(int mode, float x, V3 g, float lo, float hi) {
+  const float gamma = (float)(1.0 / 2.33), gm1 = (float)(1.0 / 2.33 - 1.0);
+  const float gy = (g.x + g.y) + g.z;                    // grad of expand(-1, H, W, 3): the channels add up
+  NormBwdTerms o;
+  if (mode == RM_MODE_LAPLACIAN) {
+    const float u = (((x / hi) * -1.0f) + 1.0f) / 2.0f;
+    const float xc = t_clamp(u, 0.0f, 1.0f);
+    const float mask = (u >= 0.0f && u <= 1.0f) ? 1.0f : 0.0f;
+    const float gu = (gy * (gamma * rm_pow(xc, gm1))) * mask;
+    const float ga = (gu * 0.5f) * -1.0f;
+    o.ga = ga / hi;
+    o.t1 = ga * (-x / (hi * hi));
+    o.top = fabsf(x) == hi;
+    o.bottom = false;
+  } else {
+    const float r = hi - lo, a = x - lo;
+    const float gx = gy * (gamma * rm_pow(a / r, gm1));
+    o.ga = gx / r;
+    o.t1 = (-gx * a) / (r * r);
+    o.top = x == hi;
+    o.bottom = x == lo;
+  }
+  return o;
+}
+
+RM_DEV float block_sum_256(float v, float* red) {      // fixed tree over the 256 threads of a block
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+__global__ void __launch_bounds__(256) k_shade_norm_bwd_a(const float* __restrict__ raw, const float* __restrict__ grad_image,
+                                                          const float* __restrict__ lohi, int mode, float* __restrict__ out,
+                                                          float* __restrict__ partials, int64_t n) {
+  __shared__ float red[256];
+  const float lo = lohi[0], hi = lohi[1];
+  float s_t1 = 0.0f, s_ga = 0.0f, c_top = 0.0f, c_bot = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const NormBwdTerms t = norm_bwd_terms(mode, raw[3 * i], load3(grad_image, i), lo, hi);
+    out[3 * i] = t.ga;
+    s_t1 += t.t1; s_ga += t.ga;
+    c_top += t.top ? 1.0f : 0.0f; c_bot += t.bottom ? 1.0f : 0.0f;      // exact below 2^24 pixels per thread
+  }
+  const float a = block_sum_256(s_t1, red), b = block_sum_256(s_ga, red), c = block_sum_256(c_top, red), d = block_sum_256(c_bot, red);
+  if (threadIdx.x == 0) {
+    float* dst = partials + 4 * blockIdx.x;
+    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_shade_norm_bwd_b(const float* __restrict__ raw, const float* __restrict__ lohi, int mode,
+                                                          float* __restrict__ out, const float* __restrict__ partials,
+                                                          int n_partials, int64_t n) {
+  __shared__ float tot[4];
+  if (threadIdx.x < 4) {            // counts are sums of integers held in floats: exact; the two float sums in block order
+    float s = 0.0f;
+    for (int b = 0; b < n_partials; ++b) s += partials[4 * b + threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const float lo = lohi[0], hi = lohi[1];
+  const float g_r = tot[0], n_top = tot[2], n_bot = tot[3];
+  const float g_lo = -tot[1] - g_r;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = raw[3 * i];
+    float v = out[3 * i];
+    if (mode == RM_MODE_LAPLACIAN) {
+      v = v + ((fabsf(x) == hi) ? (g_r / n_top) * sgn0(x) : 0.0f);
+    } else {
+      v = (v + ((x == hi) ? g_r / n_top : 0.0f)) + ((x == lo) ? g_lo / n_bot : 0.0f);
+    }
+    out[3 * i] = v; out[3 * i + 1] = 0.0f; out[3 * i + 2] = 0.0f;
+  }
+}
+
 // workspace: words 0-2 global min / max / NaN flag, the rest zero (tile queue counters)
 __global__ void k_minmax_init(uint32_t* mm) {
   mm += (size_t)blockIdx.x * RM_WORK_WORDS;       // one block per workspace (rm_minmax_init_many)

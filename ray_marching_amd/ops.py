@@ -522,9 +522,15 @@ class Render(torch.autograd.Function):
             raw3, lohi, across_ranks = ctx.lap
             if across_ranks:
                 raise NotImplementedError("gradient of a globally normalised shader through a minimum / maximum taken across ranks")
-            graw = laplacian_normalisation_vjp(g, raw3[..., 0], lohi[1]) if ctx.mode == 5 \
-                else minmax_normalisation_vjp(g, raw3[..., 0], lohi[0], lohi[1])
-            g = torch.stack([graw, torch.zeros_like(graw), torch.zeros_like(graw)], dim=-1).contiguous()
+            # rm_shade_norm_backward: two launches (block sums + the elementwise combination) in place of the ~15 tensor
+            # ops of minmax_normalisation_vjp / laplacian_normalisation_vjp below, which stay as its readable statement
+            graw3 = torch.empty_like(raw3)
+            part = torch.empty(_abi.NORM_BWD_BLOCKS * 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(_lib.rm_shade_norm_backward(_abi.ptr(raw3), _abi.ptr(g), _abi.ptr(lohi), ctx.mode, _abi.ptr(graw3),
+                                                       _abi.ptr(part), raw3.numel() // 3, _abi.current_stream(dev)),
+                           "rm_shade_norm_backward")
+            g = graw3
         gprm = torch.empty(max(cs.n_params, 1), dtype=torch.float32, device=dev)
         lib = cs.lib(True, ctx.precision)
         with torch.cuda.device(dev):

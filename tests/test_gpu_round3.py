@@ -239,3 +239,42 @@ def test_training_step_helper_matches_the_eager_loop():
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (la, lb)
     for a, b in zip(pa, pb):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("mode", [1, 2, 5])
+def test_shade_norm_backward_kernel_matches_the_tensor_formulas(mode):
+    """rm_shade_norm_backward (two launches) against ops.minmax_normalisation_vjp / laplacian_normalisation_vjp (the
+    same VJP written as ~15 tensor operations in the order autograd walks it): finite values to summation order,
+    infinities and NaNs at exactly the same pixels -- on a frame with several pixels at the minimum and at the
+    maximum, and on one whose upstream gradient is zero at the extremal pixels (0 * inf)."""
+    from ray_marching_amd import _abi, ops
+    gen = torch.Generator().manual_seed(31 + mode)
+    n = 37 * 53
+    for variant in range(3):
+        raw = torch.randn(n, generator=gen) * (2.0 if mode == 5 else 0.5)
+        if mode != 5:
+            raw = raw - 1.0
+        idx = torch.randperm(n, generator=gen)
+        raw[idx[:3]] = raw.max() if mode != 5 else raw.abs().max() * (1.0 if variant else -1.0)   # several pixels at the extremum
+        raw[idx[3:5]] = raw.min()
+        g = torch.randn(n, 3, generator=gen)
+        if variant == 2:
+            g[idx[:5]] = 0.0
+        raw3 = raw[:, None].expand(n, 3).contiguous().to(DEV)
+        g = g.to(DEV)
+        lo, hi = (raw.min(), raw.max()) if mode != 5 else (raw.min(), raw.abs().max())
+        lohi = torch.stack([lo, hi]).to(DEV)
+        want = ops.laplacian_normalisation_vjp(g, raw3[:, 0], lohi[1]) if mode == 5 \
+            else ops.minmax_normalisation_vjp(g, raw3[:, 0], lohi[0], lohi[1])
+        out = torch.empty_like(raw3)
+        part = torch.empty(_abi.NORM_BWD_BLOCKS * 4, device=DEV)
+        _abi.check(_abi.lib.rm_shade_norm_backward(_abi.ptr(raw3), _abi.ptr(g), _abi.ptr(lohi), mode, _abi.ptr(out),
+                                                   _abi.ptr(part), n, _abi.current_stream(torch.device(DEV))), "rm_shade_norm_backward")
+        got = out[:, 0]
+        assert torch.equal(out[:, 1:], torch.zeros_like(out[:, 1:]))
+        assert torch.equal(got.isnan(), want.isnan()) and torch.equal(got.isinf(), want.isinf()), (mode, variant)
+        fin = torch.isfinite(want)
+        assert torch.equal(torch.sign(got[~fin & ~want.isnan()]), torch.sign(want[~fin & ~want.isnan()]))
+        scale = float(want[fin].abs().max()) if fin.any() else 1.0
+        assert float((got[fin] - want[fin]).abs().max()) <= 2e-5 * scale + 1e-7, (mode, variant)
+        assert int((~fin).sum()) > 0 or mode == 5          # the distance / proximity VJPs always carry non-finite entries
