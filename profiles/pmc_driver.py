@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=H, focal_length=PX * H,
                   sensor_width=PX * W, sensor_height=PX * H, normals_eps=5e-2, regen=False).to(dev)   # the tile kernel only
 q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
-t = torch.tensor([[0.0, 0.0, -3.0]], device=dev)
+t = torch.tensor([[0.0, 0.0, float(sys.argv[1]) if len(sys.argv) > 1 else -3.0]], device=dev)     # camera z (default -3)
 with torch.no_grad():
     for _ in range(4):
         loop.camera(q, t)                     # calibration: 49.8 MB read, 49.8 MB written

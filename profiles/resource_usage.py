@@ -43,7 +43,8 @@ print(f"# {'kernel':58s} VGPR AGPR SGPR  spillS spillV scratch[B]  occ[waves/SIM
 for k in rows:
     short = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
     short = re.sub(r"\(.*", "", short.replace("void ", "").replace("rm::", ""))
-    short = re.sub(r"StaticCfg<RmStaticCode, (\d+)>", r"S\1", short)
+    short = re.sub(r"StaticCfg<RmStaticCode, (\d+), false>", r"S\1", short)
+    short = re.sub(r"StaticCfg<RmStaticCode, (\d+), true>", r"S\1v", short)      # v: parameters in VGPRs
     if not short.startswith("k_"):
         continue
     print(f"{short[:60]:60s} {k.get('VGPRs', '?'):>4s} {k.get('AGPRs', '?'):>4s} {k.get('TotalSGPRs', '?'):>4s}  {k.get('SGPRs Spill', '?'):>6s} "

@@ -60,6 +60,11 @@ using G = rm::StaticCfg<RmStaticCode>;
 #define RM_BWD_REG_PARAMS 64
 #endif
 using GB = rm::StaticCfg<RmStaticCode, RM_BWD_REG_PARAMS>;   // backward kernels: parameter floats kept in SGPRs up to this many
+// the tile frame kernel of scenes with few parameters keeps them in VGPRs (rm_device.h: RegParams)
+#ifndef RM_FWD_VGPR_PARAM_LIMIT
+#define RM_FWD_VGPR_PARAM_LIMIT 32
+#endif
+using GF = rm::StaticCfg<RmStaticCode, 64, (RmStaticCode::n_params + RmStaticCode::n_derived <= RM_FWD_VGPR_PARAM_LIMIT)>;
 // static path: parameter block + (backward) one accumulator row per wave for the block reduction
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
@@ -75,6 +80,7 @@ int check_static(const RmScene* sc) {
 #else
 using G = rm::GenericCfg;
 using GB = rm::GenericCfg;
+using GF = rm::GenericCfg;
 int check_static(const RmScene*) { return RM_OK; }
 // LDS bytes of the generic path for a block of `block` threads.
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
@@ -373,7 +379,7 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     return launched("k_render_finish");
   }
   Launch L;
-  if (int e = pick_launch(rm::k_render_fwd<G>, *scene, false, tune_block(), &L)) return e;
+  if (int e = pick_launch(rm::k_render_fwd<GF>, *scene, false, tune_block(), &L)) return e;
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
   if (tune_max_blocks() > 0 && (flags & RM_FLAG_DYNAMIC_TILES) && minmax && !env_set("RM_MAX_BLOCKS")) {
@@ -383,14 +389,14 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     // band); (2) at least ~2 tiles per wave, or the dynamic queues have nothing to balance with (512^2 frame,
     // closed scene 1: 1280 -> 512 blocks, 228 -> 177 us).
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<G>, L.block, L.lds) == hipSuccess && per_cu > 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<GF>, L.block, L.lds) == hipSuccess && per_cu > 0) {
       const int resident = per_cu * cu_count();
       if (grid > resident) grid = resident;
     }
     const int64_t two_per_wave = (wave_tiles / 2 + (L.block >> 6) - 1) / (L.block >> 6);
     if (grid > two_per_wave) grid = (int)(two_per_wave < 1 ? 1 : two_per_wave);
   }
-  rm::k_render_fwd<G><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  rm::k_render_fwd<GF><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_fwd")) return e;
   if (park) {
     Launch LP;

@@ -246,16 +246,24 @@ struct LdsParams {
   RM_DEV V3 v3(int i) const { return V3{p[i], p[i + 1], p[i + 2]}; }
 };
 
-template <int N>
+// kVgpr: keep the copies in VGPRs instead.  An SGPR source operand makes its consumer a half-rate instruction
+// (profiles/r03_valu_issue_bench.txt: v_sub |v|,s 4.1 cycles against 2.3 for |v|,v) and 106 SGPRs do not hold 25 parameters
+// plus everything else, so the SGPR version spills (v_readlane / v_writelane per use).  Measured on the config-2 tile kernel
+// (profiles/r03_ab_vgpr_params.txt): 127.5 -> 108.5 M executed VALU wave-instructions, 248 -> 235 us at (0,0,-3) and
+// 493 -> 463 us at (0,0,1) under rocprofv3; but +22 VGPRs per kernel: the ray pools got 29 % slower and the backward
+// kernels lose their last wave of occupancy, so only k_render_fwd of scenes with few parameters takes it.
+template <int N, bool kVgpr = false>
 struct RegParams {
   float v[N > 0 ? N : 1];
   RM_DEV void load(const float* lds) {
 #pragma unroll
-#if defined(RM_VGPR_PARAMS)   // experiment knob: VGPR-resident copies (measured: no gain, +20 VGPRs)
-    for (int i = 0; i < N; ++i) v[i] = lds[i];
+    for (int i = 0; i < N; ++i) {
+#if defined(RM_VGPR_PARAMS)   // experiment knob: VGPR-resident copies in every kernel
+      v[i] = lds[i];
 #else
-    for (int i = 0; i < N; ++i) v[i] = uniform_f(lds[i]);
+      v[i] = kVgpr ? lds[i] : uniform_f(lds[i]);
 #endif
+    }
   }
   RM_DEV float operator[](int i) const { return v[i]; }
   RM_DEV V3 v3(int i) const { return V3{v[i], v[i + 1], v[i + 2]}; }

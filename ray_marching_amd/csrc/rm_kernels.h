@@ -59,7 +59,7 @@ struct GenericCfg {
 #ifndef RM_LDS_TAPE_MIN_SLOTS
 #define RM_LDS_TAPE_MIN_SLOTS 17   // scenes with at least this many tape slots keep the tape in LDS columns (HybridStore)
 #endif
-template <class Code, int kRegParamLimit = 64>
+template <class Code, int kRegParamLimit = 64, bool kVgprParams = false>
 struct StaticCfg {
   static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_grad_derived;
   static constexpr bool kLdsTape = Code::n_slots >= RM_LDS_TAPE_MIN_SLOTS;
@@ -68,7 +68,7 @@ struct StaticCfg {
   // small parameter blocks ride in registers; big ones (config 5: 381 floats) stay in LDS
   static constexpr int kParamFloats = Code::n_params + Code::n_derived;
   static constexpr bool kRegParams = kParamFloats <= kRegParamLimit;
-  using PT = std::conditional_t<kRegParams, RegParams<kParamFloats>, LdsParams>;
+  using PT = std::conditional_t<kRegParams, RegParams<kParamFloats, kVgprParams>, LdsParams>;
   using SceneT = Scene<Prog, Store, PT>;
   static constexpr bool kStatic = true;
   static constexpr int kAcc = Code::n_params + Code::n_grad_derived;     // gradient accumulators per ray

@@ -191,54 +191,40 @@ def test_config4_full_size_properties(monkeypatch):
 
 
 def test_training_step_helper_matches_the_eager_loop():
-    """RenderLoop.training_step: forward -> loss -> backward -> SGD captured into one HIP graph on first use.  Five
-    iterations with a pose that changes every iteration follow the same trajectory as the eager loop (losses and
-    parameters to summation order), and torch raises no stream-mismatch warning anywhere."""
+    """RenderLoop.training_step: forward -> loss -> backward -> SGD captured into one HIP graph on first use.  Over five
+    iterations with a pose that changes every iteration, each replayed step equals the eager step taken from the same
+    parameters (loss and updated parameters to summation order; whole trajectories are not compared: one silhouette pixel
+    flipping on a 1e-8 parameter difference moves this 64x64 MSE by 1e-4), and torch raises no stream-mismatch warning."""
     from ray_marching_amd.scene.scene_registry import make_closed_test_scene
     h = w = 64
     target = torch.rand(1, h, w, 1, generator=torch.Generator().manual_seed(9)).to(DEV)
     loss_fn = lambda image: (image[..., :1] - target).pow(2).mean()
     poses = [(torch.nn.functional.normalize(torch.tensor([[1.0, 0.01 * i, -0.02 * i, 0.0]]), dim=-1).to(DEV),
               torch.tensor([[0.02 * i, 0.0, -1.0 - 0.05 * i]], device=DEV)) for i in range(5)]
-
-    def run(captured):
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
         scene = make_closed_test_scene()
         loop = H.make_loop(scene, h, w)
         opt = torch.optim.SGD(scene.parameters(), lr=1e-2)
-        losses = []
-        step = loop.training_step(loss_fn, mode=0, marching_steps=32, optimizer=opt) if captured else None
+        step = loop.training_step(loss_fn, mode=0, marching_steps=32, optimizer=opt)
+        twin = make_closed_test_scene()
+        twin_loop = H.make_loop(twin, h, w)
+        twin_opt = torch.optim.SGD(twin.parameters(), lr=1e-2)
+        step(*poses[0])                                  # first call: two warm-up iterations, the capture, one replay
+        start = [p.detach().clone() for p in make_closed_test_scene().to(DEV).parameters()]
+        assert any(float((a - b).abs().max()) > 0 for a, b in zip(start, scene.parameters())), "the optimiser is part of the graph"
         for q, t in poses:
-            if captured:
-                losses.append(float(step(q, t)))
-            else:
-                opt.zero_grad(set_to_none=True)
-                loss = loss_fn(loop(q, t, 0, 1, 32))
-                loss.backward()
-                opt.step()
-                losses.append(float(loss))
-        return losses, [p.detach().clone() for p in scene.parameters()]
-
-    with warnings.catch_warnings():
-        warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
-        # (the capture's two warm-up calls are real iterations at the first pose, optimiser steps included: the eager loop
-        #  below takes the same two extra steps)
-        la, pa = run(True)
-    scene = make_closed_test_scene()
-    loop = H.make_loop(scene, h, w)
-    opt = torch.optim.SGD(scene.parameters(), lr=1e-2)
-    lb = []
-    for i, (q, t) in enumerate([poses[0]] * 2 + poses):
-        opt.zero_grad(set_to_none=True)
-        loss = loss_fn(loop(q, t, 0, 1, 32))
-        loss.backward()
-        opt.step()
-        if i >= 2:
-            lb.append(float(loss))
-    pb = [p.detach().clone() for p in scene.parameters()]
-    for a, b in zip(la, lb):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (la, lb)
-    for a, b in zip(pa, pb):
-        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+            with torch.no_grad():
+                for a, b in zip(twin.parameters(), scene.parameters()):
+                    a.copy_(b)
+            got_loss = float(step(q, t))
+            twin_opt.zero_grad(set_to_none=True)
+            want = loss_fn(twin_loop(q, t, 0, 1, 32))
+            want.backward()
+            twin_opt.step()
+            assert abs(got_loss - float(want)) <= 1e-6 * max(1.0, abs(float(want))), (got_loss, float(want))
+            for a, b in zip(scene.parameters(), twin.parameters()):
+                assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
 
 
 @pytest.mark.parametrize("mode", [1, 2, 5])
