@@ -236,8 +236,18 @@ def reference_shape_probe(dev):
                 loop(q, t, mode, 1, steps)
             torch.cuda.synchronize()
             render = (time.perf_counter() - t0) / n * 1e3
+            # RenderLoop.display_frame: the frame kernel stores the [H,W,4] fp32 display tensor itself (one launch)
+            for _ in range(10):
+                loop.display_frame(q, t, mode, 1, steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                loop.display_frame(q, t, mode, 1, steps)
+                torch.cuda.synchronize()
+            fused_waited = (time.perf_counter() - t0) / n * 1e3
             out["modes"][name] = {"ms_per_frame": free, "fps": 1e3 / free, "ms_per_frame_waited": waited,
                                   "fps_waited": 1e3 / waited, "render_only_ms": render,
+                                  "display_frame_ms_waited": fused_waited, "display_frame_fps_waited": 1e3 / fused_waited,
                                   "Mrays_per_s": h * w / free / 1e3}
     return out
 

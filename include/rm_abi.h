@@ -35,8 +35,13 @@ extern "C" {
 enum {
   RM_DTYPE_F32 = 0,
   RM_DTYPE_F16 = 1,      /* IEEE binary16 storage, fp32 arithmetic */
-  RM_DTYPE_F64 = 2       /* images / colormap of the tangent and spin shaders only: the reference multiplies an
+  RM_DTYPE_F64 = 2,      /* images / colormap of the tangent and spin shaders only: the reference multiplies an
                             fp32 brightness by its float64 colormap, giving a float64 image (shader.py:104,118) */
+  RM_DTYPE_RGBA_F32 = 3  /* image of rm_render_forward / rm_shade_finish only, one camera: [rows,W,4] fp32 = the display
+                            contract of main.py:78-84, F.pad(images.mean(0).float(), [0,1], 1.0) (torchwindow/window.py:146-174:
+                            contiguous RGBA32F, row pitch 16 W) written by the frame kernel itself -- the pixel rounded to the
+                            type the image would have had (cam->dtype; float64 for modes 6, 7 with a float64 colormap), then
+                            to fp32, alpha = 1 */
 };
 
 enum {
@@ -295,7 +300,9 @@ int rm_minmax_encode(const float* lohi /*device [2]*/, uint32_t* minmax, void* s
 /* second pass of the globally normalised shaders (modes 1, 2, 5): first_pass fp32 [n_pixels,3] -> image
  * [n_pixels,3] of image_dtype (F32 or F16); in place when the two pointers are equal (F32 only). */
 int rm_shade_finish(const float* first_pass, void* image, int32_t image_dtype, int64_t n_pixels,
-                    const uint32_t* minmax, int32_t mode, void* stream);
+                    const uint32_t* minmax, int32_t mode,
+                    int32_t round_dtype /*RGBA_F32 images: F16 rounds the value through binary16 first (a .half() module); else F32*/,
+                    void* stream);
 
 /* Shader.forward on tensors (rendering/shader.py:190-263): first pass for every mode.
  * Inputs (fp32) a mode does not read may be NULL.  frames: [N,3,3]; per-pixel arrays hold

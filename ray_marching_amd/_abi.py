@@ -29,7 +29,7 @@ OP_CULL_LSE = 18
 
 FLAG_EARLY_OUT, FLAG_TILE8X8, FLAG_DYNAMIC_TILES, FLAG_REGEN, FLAG_ORDER_PER_RAY = 1, 2, 4, 8, 16
 ORDER_ONE_BLOCK, ORDER_SCRATCH_INTS = 131072, 8192
-DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2      # RM_DTYPE_*
+DTYPE_F32, DTYPE_F16, DTYPE_F64, DTYPE_RGBA_F32 = 0, 1, 2, 3      # RM_DTYPE_*
 _DTYPES = {torch.float32: DTYPE_F32, torch.float16: DTYPE_F16, torch.float64: DTYPE_F64}
 
 
@@ -86,7 +86,7 @@ _SIGNATURES = {
     "rm_minmax_init_many": (C.c_int, [_P, C.c_int32, _P]),
     "rm_minmax_decode": (C.c_int, [_P, _P, _P]),
     "rm_minmax_encode": (C.c_int, [_P, _P, _P]),
-    "rm_shade_finish": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
+    "rm_shade_finish": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "rm_shade_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
     "rm_shade_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int64, _P]),

@@ -366,9 +366,19 @@ class RenderLoop(nn.Module):
         from .graphs import CapturedTrainingStep
         return CapturedTrainingStep(self, loss_fn, mode, degree, marching_steps, optimizer, pose_requires_grad)
 
+    def display_frame(self, orientations: Tensor, translations: Tensor, mode: int = 0, degree: int = 1,
+                      marching_steps: int = 32) -> Tensor:
+        """What main.py:78-84 hands to ``Window.draw`` -- ``F.pad(images.mean(dim=0).float(), [0, 1], value=1.0)``:
+        contiguous [H, W, 4] float32, alpha 1 (torchwindow/window.py:146-174) -- written by the frame kernel itself
+        instead of by three tensor passes over the image (mean, cast, pad).  One camera, inference only; bit-identical
+        with the three passes (tests/test_gpu_round3.py).  Batches of cameras go through ``forward`` + headless.to_rgba."""
+        with torch.no_grad():
+            return self.forward(orientations, translations, mode, degree, marching_steps, _image_dtype="rgba")
+
     @torch.compiler.disable      # main.py:44 wraps the loop in torch.compile: Dynamo steps over the ctypes launches (eager bits, no Inductor kernel)
     def forward(self, orientations: Tensor, translations: Tensor, mode: int = 0, degree: int = 1,
-                marching_steps: int = 32, rows=None, allreduce_minmax=None, tile_order=None, tile_cost=None):
+                marching_steps: int = 32, rows=None, allreduce_minmax=None, tile_order=None, tile_cost=None,
+                _image_dtype=None):
         """-> image [N, H, W, 3] in the module's dtype (modes 6, 7: promoted with the colormap's, float64 for
         the reference's data file).  ``rows=(r0, r1)`` renders only that pixel-row band ([N, r1-r0, W, 3]);
         ``allreduce_minmax`` is the hook row-tiled multi-GPU rendering uses for the global min/max of modes
@@ -417,9 +427,11 @@ class RenderLoop(nn.Module):
                 leaves = cs.leaves      # their gradients still go to the leaves
         image = ops.render_frame(params, orientations, translations, cs, rp, rd,
                                  self.normals.tetra(), cmap, mode, int(degree), int(marching_steps), rows,
-                                 flags, allreduce_minmax, self.precision, None, tile_order, tile_cost, leaves, events)
+                                 flags, allreduce_minmax, self.precision, _image_dtype, tile_order, tile_cost, leaves, events)
         if after is not None:
             after()
+        if _image_dtype == "rgba":
+            return image
         out_dtype = self.camera.ray_positions.dtype
         if mode in (6, 7):
             out_dtype = torch.promote_types(out_dtype, self.shader.cyclic_cmap.dtype)

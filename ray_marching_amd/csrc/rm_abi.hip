@@ -55,7 +55,11 @@ struct Launch {
 };
 
 #ifdef RM_STATIC_CODE
-using G = rm::StaticCfg<RmStaticCode>;
+#ifndef RM_FWD_REG_PARAMS
+#define RM_FWD_REG_PARAMS 32      // forward kernels: parameter floats hoisted into SGPRs up to this many, LDS reads beyond (closed scene 1, 51 floats:
+                                  // 225 SGPR spills as registers; training step 0.401 -> 0.394 ms at 512^2, 0.878 -> 0.838 at 1024^2, profiles/r03_train_ab.txt)
+#endif
+using G = rm::StaticCfg<RmStaticCode, RM_FWD_REG_PARAMS>;
 #ifndef RM_BWD_REG_PARAMS
 #define RM_BWD_REG_PARAMS 64
 #endif
@@ -64,7 +68,7 @@ using GB = rm::StaticCfg<RmStaticCode, RM_BWD_REG_PARAMS>;   // backward kernels
 #ifndef RM_FWD_VGPR_PARAM_LIMIT
 #define RM_FWD_VGPR_PARAM_LIMIT 32
 #endif
-using GF = rm::StaticCfg<RmStaticCode, 64, (RmStaticCode::n_params + RmStaticCode::n_derived <= RM_FWD_VGPR_PARAM_LIMIT)>;
+using GF = rm::StaticCfg<RmStaticCode, RM_FWD_REG_PARAMS, (RmStaticCode::n_params + RmStaticCode::n_derived <= RM_FWD_VGPR_PARAM_LIMIT)>;
 // static path: parameter block + (backward) one accumulator row per wave for the block reduction
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
@@ -326,8 +330,10 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a minmax workspace and a first_pass buffer", mode);
   if (mapped && (!cmap || cmap_size <= 0 || cmap_dtype < RM_DTYPE_F32 || cmap_dtype > RM_DTYPE_F64))
     return fail(RM_E_BADARG, "rm_render_forward: mode %d needs a colormap (F32, F16 or F64)", mode);
-  if (!(io_dtype_ok(image_dtype) || (image_dtype == RM_DTYPE_F64 && mapped)))
-    return fail(RM_E_BADARG, "rm_render_forward: image dtype %d (F64 only for modes 6, 7)", image_dtype);
+  if (!(io_dtype_ok(image_dtype) || (image_dtype == RM_DTYPE_F64 && mapped) || (image_dtype == RM_DTYPE_RGBA_F32 && cam->num_cameras == 1)))
+    return fail(RM_E_BADARG, "rm_render_forward: image dtype %d (F64 only for modes 6, 7; RGBA_F32 only for one camera)", image_dtype);
+  if (image_dtype == RM_DTYPE_RGBA_F32 && (reinterpret_cast<uintptr_t>(image) & 15))
+    return fail(RM_E_BADARG, "rm_render_forward: an RGBA_F32 image must be 16-byte aligned");
   rm::RenderArgs a;
   memset(&a, 0, sizeof(a));
   a.scene = *scene; a.cam = *cam; a.tetra = *tetra;
@@ -444,15 +450,16 @@ int rm_minmax_encode(const float* lohi, uint32_t* minmax, void* stream) {
 }
 
 int rm_shade_finish(const float* first_pass, void* image, int32_t image_dtype, int64_t n_pixels, const uint32_t* minmax,
-                    int32_t mode, void* stream) {
+                    int32_t mode, int32_t round_dtype, void* stream) {
   if (!first_pass || !image || !minmax || n_pixels < 0) return fail(RM_E_BADARG, "rm_shade_finish: bad args");
-  if (!io_dtype_ok(image_dtype) || (image_dtype != RM_DTYPE_F32 && (const void*)first_pass == (const void*)image))
+  if (!(io_dtype_ok(image_dtype) || image_dtype == RM_DTYPE_RGBA_F32) || !io_dtype_ok(round_dtype) ||
+      (image_dtype != RM_DTYPE_F32 && (const void*)first_pass == (const void*)image))
     return fail(RM_E_BADARG, "rm_shade_finish: image dtype %d (in place only for F32)", image_dtype);
   if (!(mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN))
     return fail(RM_E_BADARG, "rm_shade_finish: mode %d has no second pass", mode);
   if (n_pixels == 0) return RM_OK;
   int grid = grid_for((n_pixels + 255) / 256, kMaxBlocks);
-  rm::k_shade_finish<<<grid, 256, 0, (hipStream_t)stream>>>(first_pass, image, image_dtype, n_pixels, minmax, mode);
+  rm::k_shade_finish<<<grid, 256, 0, (hipStream_t)stream>>>(first_pass, image, image_dtype, n_pixels, minmax, mode, round_dtype);
   return launched("k_shade_finish");
 }
 

@@ -798,9 +798,18 @@ RM_DEV Shaded domain_colour(float re, float im, int size, int degree) {
 
 // brightness.mul(colours) (shader.py:118): fp32 brightness times a float64 colormap row is a float64 product
 // (type promotion), times an fp32 / fp16 row a product in that type.
-RM_DEV void store_shaded(void* image, int image_dt, int64_t li, const Shaded& s, const void* cmap, int cmap_dt) {
+// RM_DTYPE_RGBA_F32: what `images.mean(0).float()` padded with alpha 1 holds for ONE camera -- the value rounded to the
+// type the [N,H,W,3] image would have had (`round_dt`: the module's dtype, or float64 for a float64 colormap product),
+// then to fp32
+RM_DEV void store_rgba(void* image, int64_t li, V3 c, int round_dt) {
+  if (round_dt == RM_DTYPE_F16) c = mk3((float)(_Float16)c.x, (float)(_Float16)c.y, (float)(_Float16)c.z);
+  *reinterpret_cast<float4*>(static_cast<float*>(image) + 4 * li) = make_float4(c.x, c.y, c.z, 1.0f);
+}
+
+RM_DEV void store_shaded(void* image, int image_dt, int64_t li, const Shaded& s, const void* cmap, int cmap_dt, int round_dt = RM_DTYPE_F32) {
   if (s.idx < 0) {
     if (image_dt == RM_DTYPE_F32) store3(static_cast<float*>(image), li, s.rgb);
+    else if (image_dt == RM_DTYPE_RGBA_F32) store_rgba(image, li, s.rgb, round_dt);
     else store3_t(image, li, s.rgb, image_dt);
     return;
   }
@@ -811,13 +820,18 @@ RM_DEV void store_shaded(void* image, int image_dt, int64_t li, const Shaded& s,
     if (image_dt == RM_DTYPE_F64) {
       double* o = static_cast<double*>(image) + 3 * li;
       o[0] = r0; o[1] = r1; o[2] = r2;
+    } else if (image_dt == RM_DTYPE_RGBA_F32) {
+      store_rgba(image, li, mk3((float)r0, (float)r1, (float)r2), RM_DTYPE_F32);     // float64 image .float()
     } else {
       store3_t(image, li, mk3((float)r0, (float)r1, (float)r2), image_dt);
     }
     return;
   }
   const V3 c = load3_t(cmap, s.idx, cmap_dt);
-  store3_t(image, li, mk3(s.bright * c.x, s.bright * c.y, s.bright * c.z), image_dt);
+  // (brightness in the module's type times a colormap row of cmap_dt: torch's type promotion -- fp16 x fp16 stays fp16)
+  const V3 prod = mk3(s.bright * c.x, s.bright * c.y, s.bright * c.z);
+  if (image_dt == RM_DTYPE_RGBA_F32) store_rgba(image, li, prod, (round_dt == RM_DTYPE_F16 && cmap_dt == RM_DTYPE_F16) ? RM_DTYPE_F16 : RM_DTYPE_F32);
+  else store3_t(image, li, prod, image_dt);
 }
 
 struct ShadeIn {
@@ -1020,7 +1034,7 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   const bool global = (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN);
   if (r.live) {
     if (global) store3(a.first_pass, r.li, out);          // rm_shade_finish normalises into `image`
-    else store_shaded(a.image, a.image_dtype, r.li, sh, a.cmap, a.cmap_dtype);
+    else store_shaded(a.image, a.image_dtype, r.li, sh, a.cmap, a.cmap_dtype, a.cam.dtype);
     if (store_p && a.p_final) store3(a.p_final, r.li, p);
     if (a.nexec) a.nexec[r.li] = nexec;
     if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
@@ -1487,7 +1501,8 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const int32_t* __restric
 }
 
 // second pass for the globally normalised shaders
-__global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n, const uint32_t* __restrict__ minmax, int mode) {
+__global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n, const uint32_t* __restrict__ minmax, int mode,
+                               int round_dt) {
   float lo, hi;
   load_minmax(minmax, lo, hi);
   const float gamma = (float)(1.0 / 2.33);
@@ -1499,7 +1514,8 @@ __global__ void k_shade_finish(const float* src, void* image, int dt, int64_t n,
     } else {                           // shader.py:34-38 / 51-55
       y = rm_pow((x - lo) / (hi - lo), gamma);
     }
-    store3_t(image, i, mk3(y, y, y), dt);
+    if (dt == RM_DTYPE_RGBA_F32) store_rgba(image, i, mk3(y, y, y), round_dt);
+    else store3_t(image, i, mk3(y, y, y), dt);
   }
 }
 

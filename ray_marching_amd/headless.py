@@ -62,7 +62,8 @@ class PosePlayer:
 
 
 def to_rgba(images: torch.Tensor) -> torch.Tensor:
-    """What main.py:78-84 hands to Window.draw: mean over cameras, fp32, alpha = 1 -> [H, W, 4]."""
+    """What main.py:78-84 hands to Window.draw: mean over cameras, fp32, alpha = 1 -> [H, W, 4].  (For one camera
+    RenderLoop.display_frame lets the frame kernel write this tensor itself.)"""
     return F.pad(images.mean(dim=0).float(), pad=[0, 1], value=1.0)
 
 
@@ -127,7 +128,7 @@ class FrameSink:
                 ev.synchronize()
 
 
-def run_headless(render_loop, events, window: FrameSink, max_frames: int):
+def run_headless(render_loop, events, window: FrameSink, max_frames: int, fused_display: bool = False):
     """The body of main.py:53-88 with the stand-ins above.  Returns frames per second."""
     import time
     t0 = time.time()
@@ -135,8 +136,11 @@ def run_headless(render_loop, events, window: FrameSink, max_frames: int):
     with torch.no_grad():
         while events.running and n < max_frames:
             positions, orientations, mode, degree, marching_steps, _ = events.get_state()
-            images = render_loop(orientations, positions, mode, degree, marching_steps)
-            window.draw(to_rgba(images))
+            if fused_display and orientations.shape[0] == 1:      # the frame kernel writes the [H,W,4] display tensor itself
+                window.draw(render_loop.display_frame(orientations, positions, mode, degree, marching_steps))
+            else:
+                images = render_loop(orientations, positions, mode, degree, marching_steps)
+                window.draw(to_rgba(images))
             n += 1
     window.close()
     if torch.cuda.is_available():

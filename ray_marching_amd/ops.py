@@ -435,11 +435,16 @@ class Render(torch.autograd.Function):
         r0, r1 = rows if rows is not None else (0, h)
         nrows = r1 - r0
         R = n * nrows * w
+        rgba = image_dtype == "rgba"        # the display contract [rows, W, 4] fp32 (include/rm_abi.h: RM_DTYPE_RGBA_F32)
+        if rgba and (record or n != 1):
+            raise ValueError("the RGBA display frame is an inference output of ONE camera")
         if record:
             image_dtype = torch.float32
         elif image_dtype is None:
             image_dtype = torch.promote_types(rp.dtype, cmap.dtype) if (mode in (6, 7) and cmap is not None) else rp.dtype
-        image = torch.empty((n, nrows, w, 3), dtype=image_dtype, device=dev)
+        image = torch.empty((nrows, w, 4), dtype=torch.float32, device=dev) if rgba \
+            else torch.empty((n, nrows, w, 3), dtype=image_dtype, device=dev)
+        image_code = _abi.DTYPE_RGBA_F32 if rgba else _abi.dtype_code(image_dtype)
         first_pass = None
         if mode in _GLOBAL_MODES:
             # (a training frame of the Laplacian shader keeps the un-normalised values for its backward)
@@ -472,7 +477,7 @@ class Render(torch.autograd.Function):
                 ev0.record()
             lib = cs.lib(False, precision)
             _abi.check(lib.rm_render_forward(s, cam, tetra, _abi.ptr(q), _abi.ptr(t), _abi.ptr(image),
-                                             _abi.dtype_code(image_dtype), _abi.ptr(first_pass),
+                                             image_code, _abi.ptr(first_pass),
                                              _abi.ptr(p_final), _abi.ptr(traj), _abi.ptr(nexec), _abi.ptr(normal_u), _abi.ptr(minmax),
                                              _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                              0 if cmap is None else _abi.dtype_code(cmap.dtype),
@@ -492,8 +497,8 @@ class Render(torch.autograd.Function):
                 if allreduce_minmax is not None:
                     allreduce_minmax(lohi)
                     _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
-                _abi.check(_lib.rm_shade_finish(_abi.ptr(first_pass), _abi.ptr(image), _abi.dtype_code(image_dtype),
-                                                n * nrows * w, _abi.ptr(minmax), mode, stream), "rm_shade_finish")
+                _abi.check(_lib.rm_shade_finish(_abi.ptr(first_pass), _abi.ptr(image), image_code,
+                                                n * nrows * w, _abi.ptr(minmax), mode, _abi.dtype_code(rp.dtype), stream), "rm_shade_finish")
         if ctx is not None:
             ctx.have_vjp = have_vjp
             ctx.mode = mode

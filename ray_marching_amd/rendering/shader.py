@@ -101,7 +101,7 @@ def shade(mode: int, degree: int = 1, *, px_coords=None, orientation=None, frame
                 _abi.check(_lib.rm_minmax_encode(_abi.ptr(lohi), _abi.ptr(minmax), stream), "rm_minmax_encode")
             final = image if out_dtype == torch.float32 else torch.empty((n, 3), dtype=out_dtype, device=dev)
             _abi.check(_lib.rm_shade_finish(_abi.ptr(image), _abi.ptr(final), _abi.dtype_code(out_dtype), n,
-                                            _abi.ptr(minmax), mode, stream), "rm_shade_finish")
+                                            _abi.ptr(minmax), mode, _abi.DTYPE_F32, stream), "rm_shade_finish")
             image = final
     ch = 3 if mode in _THREE_CHANNEL else 1
     out = image.view(*lead, 3)[..., :ch]

@@ -264,3 +264,50 @@ def test_shade_norm_backward_kernel_matches_the_tensor_formulas(mode):
         scale = float(want[fin].abs().max()) if fin.any() else 1.0
         assert float((got[fin] - want[fin]).abs().max()) <= 2e-5 * scale + 1e-7, (mode, variant)
         assert int((~fin).sum()) > 0 or mode == 5          # the distance / proximity VJPs always carry non-finite entries
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_display_frame_is_the_three_pass_display_contract(dtype):
+    """RenderLoop.display_frame: F.pad(images.mean(0).float(), [0,1], 1.0) (main.py:78-84; Window.draw's contiguous
+    [H,W,4] fp32 input, torchwindow/window.py:146-174) written by the frame kernel itself -- bit-identical with the
+    three tensor passes for all eight shader modes, fp32 and .half() modules, both frame kernels, and one launch."""
+    import torch.nn.functional as F
+    from torch.profiler import ProfilerActivity, profile
+    h, w, steps = 90, 160, 32
+    cmap = torch.from_numpy(H.gold("cmap.npz")["cyclic_cmap"])
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV).to(dtype)
+    t = torch.tensor([[0.0, 0.0, 1.0]], device=DEV).to(dtype)
+    for regen in (False, True):
+        loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=regen)
+        loop.shader.cyclic_cmap = cmap.to(DEV)
+        loop = loop.to(dtype)                 # like main.py's .to(device, dtype): the colormap buffer is cast too
+        for mode in range(8):
+            with torch.no_grad():
+                want = F.pad(loop(q, t, mode, 2, steps).mean(dim=0).float(), pad=[0, 1], value=1.0)
+                got = loop.display_frame(q, t, mode, 2, steps)
+            assert got.shape == (h, w, 4) and got.dtype == torch.float32 and got.is_contiguous()
+            assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (regen, mode)
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w, regen=False).to(dtype)
+    with torch.no_grad():
+        for _ in range(3):
+            loop.display_frame(q, t, 4, 1, steps)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            loop.display_frame(q, t, 4, 1, steps)
+            torch.cuda.synchronize()
+    kernels = _device_kernels(prof)
+    if kernels:
+        others = [k for k in kernels if "k_render_fwd" not in k and "k_minmax_init" not in k and "Memset" not in k]
+        assert not others, others
+    # float64 colormap with an fp32 module (the reference's data file as loaded): the float64 product, then .float()
+    loop = H.make_loop(H.spec_to_module(O.scene_test2()), h, w)
+    loop.shader.cyclic_cmap = cmap.to(DEV)
+    with torch.no_grad():
+        for mode in (6, 7):
+            img = loop(q.float(), t.float(), mode, 3, steps)
+            assert img.dtype == torch.float64
+            want = F.pad(img.mean(dim=0).float(), pad=[0, 1], value=1.0)
+            assert torch.equal(torch.nan_to_num(loop.display_frame(q.float(), t.float(), mode, 3, steps), nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+    with pytest.raises(ValueError):
+        H.make_loop(H.spec_to_module(O.scene_test2()), 16, 16, n=2).display_frame(torch.tensor([[1.0, 0, 0, 0]] * 2, device=DEV),
+                                                                                  torch.zeros(2, 3, device=DEV))

@@ -52,8 +52,8 @@ def test_bad_arguments_return_error_codes_without_launching():
     assert lib.rm_sdf_forward(refs_only, None, None, 0, 1, None) == 0    # a gather table instead of the packed block
     neither = _abi.RmScene(program=16, params=None, param_refs=None, n_instr=1, n_params=1, n_derived=0, stack_floats=0, n_slots=0)
     assert lib.rm_sdf_forward(neither, None, None, 0, 0, None) == -1
-    assert lib.rm_shade_finish(None, None, 0, 10, None, 1, None) == -1
-    assert lib.rm_shade_finish(16, 16, 1, 10, 16, 1, None) == -1         # fp16 image cannot be normalised in place
+    assert lib.rm_shade_finish(None, None, 0, 10, None, 1, 0, None) == -1
+    assert lib.rm_shade_finish(16, 16, 1, 10, 16, 1, 0, None) == -1         # fp16 image cannot be normalised in place
     assert lib.rm_minmax_init(None, None) == -1
     cam = _abi.RmCamera(ray_positions=16, ray_directions=16, num_cameras=1, height=4, width=4, dtype=0)
     tet = _abi.RmTetra()
