@@ -212,7 +212,7 @@ def test_training_step_helper_matches_the_eager_loop():
         twin_opt = torch.optim.SGD(twin.parameters(), lr=1e-2)
         step(*poses[0])                                  # first call: two warm-up iterations, the capture, one replay
         start = [p.detach().clone() for p in make_closed_test_scene().to(DEV).parameters()]
-        assert any(float((a - b).abs().max()) > 0 for a, b in zip(start, scene.parameters())), "the optimiser is part of the graph"
+        assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(start, scene.parameters())), "the optimiser is part of the graph"
         for q, t in poses:
             with torch.no_grad():
                 for a, b in zip(twin.parameters(), scene.parameters()):
@@ -224,7 +224,7 @@ def test_training_step_helper_matches_the_eager_loop():
             twin_opt.step()
             assert abs(got_loss - float(want)) <= 1e-6 * max(1.0, abs(float(want))), (got_loss, float(want))
             for a, b in zip(scene.parameters(), twin.parameters()):
-                assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+                assert float((a - b).detach().abs().max()) <= 1e-6 * max(1.0, float(b.detach().abs().max()))
 
 
 @pytest.mark.parametrize("mode", [1, 2, 5])
