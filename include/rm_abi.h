@@ -227,7 +227,8 @@ int rm_camera_forward(const RmCamera* cam, const void* orientation /*device [N,4
  *   image   : device [N,rows,W,3] of image_dtype (F32, F16; F64 for modes 6,7 with a float64 colormap).
  *   p_final : nullable fp32 [N,rows,W,3]; nexec nullable int32 [N,rows,W].
  *   traj    : nullable fp32, rm_render_traj_floats(...) floats: the iterates of the march for rm_render_backward, laid
- *             out [step][component][wave tile * 64 + lane] so that every store of a wave is 256 contiguous bytes; private
+ *             out [wave tile][step][component][lane]: every store of a wave is 256 contiguous bytes and a tile's whole
+ *             trajectory one contiguous block; private
  *             to this pair of entry points.
  *   normal_u : nullable fp32 [N,rows,W,3]: the un-normalised normal of the final point (the normal is normal_u /
  *             |normal_u|); handed to rm_render_backward it saves that kernel eight scene evaluations per ray.

@@ -241,15 +241,17 @@ RM_DEV V3 step_point(V3 p, V3 v, float f) {
 #endif
 }
 
-// Where a recorded march keeps its iterates.  kSoa = false: [step][ray][3] (rm_march_forward: any list of rays).
-// kSoa = true (the fused frame): [step][component][slot] with slot = wave tile * 64 + lane and stride = 64 * wave tiles,
-// so each of the three stores of a wave is 256 contiguous bytes -- per-pixel [ray][3] rows of an 8x8 tile are eight
-// 96-byte pieces (measured: recording forward of the config-4 shape 135 us against 117 us without recording).
+// Where a recorded march keeps its iterates.  kSoa = false: [step][ray][3], stride = rays (rm_march_forward: any list
+// of rays).  kSoa = true (the fused frame): [wave tile][step][component][lane], stride = the step count, idx = the
+// ray's slot = tile * 64 + lane: each of the three stores of a wave is 256 contiguous bytes (per-pixel [ray][3] rows of an
+// 8x8 tile are eight 96-byte pieces), and the whole trajectory of a tile is ONE contiguous block of steps x 768 bytes,
+// so the forward's successive steps and the reverse sweep's walk stay inside a few pages instead of touching three new
+// ones, megabytes apart, at every step.
 template <bool kSoa>
 RM_DEV void traj_store(float* traj, int64_t stride, int64_t idx, int i, V3 p) {
   if constexpr (kSoa) {
-    float* q = traj + (int64_t)(3 * i) * stride + idx;
-    q[0] = p.x; q[stride] = p.y; q[2 * stride] = p.z;
+    float* q = traj + ((idx >> 6) * stride + i) * 192 + (idx & 63);
+    q[0] = p.x; q[64] = p.y; q[128] = p.z;
   } else {
     store3(traj + 3 * (int64_t)i * stride, idx, p);
   }
@@ -257,8 +259,8 @@ RM_DEV void traj_store(float* traj, int64_t stride, int64_t idx, int i, V3 p) {
 template <bool kSoa>
 RM_DEV V3 traj_load(const float* traj, int64_t stride, int64_t idx, int i) {
   if constexpr (kSoa) {
-    const float* q = traj + (int64_t)(3 * i) * stride + idx;
-    return mk3(q[0], q[stride], q[2 * stride]);
+    const float* q = traj + ((idx >> 6) * stride + i) * 192 + (idx & 63);
+    return mk3(q[0], q[64], q[128]);
   } else {
     return load3(traj + 3 * (int64_t)i * stride, idx);
   }
@@ -430,29 +432,46 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
   // walked 24.6 steps per wave tile on average, nearly all of them inside this tail).  The anchor is renewed
   // when some ray of the wave has moved more than tau = 1e-6 max(1, |p|) away from it; arguments of the VJP
   // differ from the reference's by <= tau, far inside the 1e-4 gradient tolerance (tests: f5_backward).
+  // Every iterate below `nexec` is a load, and a load the next wave-wide vote depends on costs its full latency (~2 us
+  // behind a 200 MB trajectory: 67 % of this kernel's wave-cycles were s_waitcnt, profiles/r03_stalls.txt).  The loop
+  // therefore keeps a WINDOW of the next eight iterates down, fetched together -- before the anchor's point-gradient
+  // evaluation, whose ~600 instructions hide them -- and consumed with constant indices.
+  V3 cur = (early && i >= 0) ? iterate(i) : p_final;           // the iterate of step i
   while (early && i >= 0) {
-    const V3 anchor = iterate(i);
+    const V3 anchor = cur;
     const float tau = 1e-6f * fmaxf(1.0f, fmaxf(fabsf(anchor.x), fmaxf(fabsf(anchor.y), fabsf(anchor.z))));
     auto near_anchor = [&](V3 q) {
       return fmaxf(fabsf(q.x - anchor.x), fmaxf(fabsf(q.y - anchor.y), fabsf(q.z - anchor.z))) <= tau;
     };
+    V3 win[8];                                                   // iterates of steps i-1 .. i-8 (the anchor where there is none)
+    auto fill = [&](int top) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) win[j] = (top - j >= 0) ? iterate(top - j) : anchor;
+    };
+    fill(i - 1);
     // how many of the next steps down stay at the anchor (for every ray of the wave)?  at least two, or the
     // plain per-step VJP below is cheaper
-    if (i < 1 || !__all(near_anchor(iterate(i - 1)))) break;
+    if (i < 1 || !__all(near_anchor(win[0]))) break;
     float f0;
     const V3 n = scene.vjp_point(anchor, 1.0f, &f0);
     float G = 0.0f;
-    bool done = false;
+    bool done = false, more = true;
     V3 p_i = anchor;
-    while (i >= 0 && __all(near_anchor(p_i))) {
-      const float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
-      if (__all(noise(gf))) { done = true; break; }
-      G = G + gf;
-      if (want_gv) gv = gv + f0 * lam;
-      lam = lam + mk3(gf * n.x, gf * n.y, gf * n.z);
-      --i;
-      if (i >= 0) p_i = iterate(i);
+    while (more) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (i < 0 || !__all(near_anchor(p_i))) { more = false; break; }
+        const float gf = (lam.x * v.x + lam.y * v.y) + lam.z * v.z;
+        if (__all(noise(gf))) { done = true; more = false; break; }
+        G = G + gf;
+        if (want_gv) gv = gv + f0 * lam;
+        lam = lam + mk3(gf * n.x, gf * n.y, gf * n.z);
+        --i;
+        p_i = win[j];                                           // the iterate of the new step i (checked above when i < 0)
+      }
+      if (more) fill(i - 1);                                    // p_i = win[7] is step i; the window moves on
     }
+    cur = p_i;
     if (__any(G != 0.0f)) scene.vjp(anchor, G);       // parameter gradients of the whole run at once
     if (walked) *walked += 2;
     if (done) { finish_frozen(i); return lam; }
@@ -619,7 +638,7 @@ struct RenderArgs {
   void* image;               // [N,rows,W,3] of image_dtype
   float* first_pass;         // modes 1, 2, 5: fp32 [N,rows,W,3] un-normalised values
   float* p_final;            // nullable
-  float* traj;               // nullable [steps][3][64 * wave tiles]  (traj_store<true>: slot = tile * 64 + lane)
+  float* traj;               // nullable [wave tile][step][3][64]  (traj_store<true>: slot = tile * 64 + lane)
   int32_t* nexec;            // nullable
   float* normal_u;           // nullable [R,3]: the un-normalised normal of the final point (training frames: the backward
                              // kernel then needs neither the four tap evaluations of the shader VJP nor those of the normalisation VJP)
@@ -1094,7 +1113,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     int nexec;
     bool parked;
     // (a recorded trajectory is indexed by the wave tile's slot, not by the pixel: traj_store<true>)
-    V3 p = march<decltype(scene), ParkToList, true>(scene, r.o, r.v, a.steps, early, a.traj, ntiles * 64,
+    V3 p = march<decltype(scene), ParkToList, true>(scene, r.o, r.v, a.steps, early, a.traj, a.steps,
                                                     a.traj ? tile * 64 + (threadIdx.x & 63) : r.li, r.live, nexec,
                                                     ParkToList{a, r.li}, &parked);
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tile] = nexec;     // nexec is wave-uniform
@@ -1925,7 +1944,7 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
       }
       int ne = a.nexec ? a.nexec[li] : a.steps;
       const int64_t tslot = tc.tile * 64 + (threadIdx.x & 63);
-      lam = march_reverse<decltype(scene), DeferToList, true>(scene, lam, v, p, a.traj, ntiles * 64, tslot, ne, a.steps,
+      lam = march_reverse<decltype(scene), DeferToList, true>(scene, lam, v, p, a.traj, a.steps, tslot, ne, a.steps,
                                                               a.grad_dirs != nullptr, gv, a.flags & RM_FLAG_EARLY_OUT, &walked,
                                                               DeferToList{a, li, tslot}, &deferred);
     }
@@ -1968,9 +1987,9 @@ RM_DEV HardItem hard_item(const RenderArgs& a, int64_t item, int groups, int H) 
   it.slot = a.hard_slot[hc];
   return it;
 }
-RM_DEV V3 hard_point(const RenderArgs& a, int64_t R64, int s, int64_t ray, int64_t slot) {
+RM_DEV V3 hard_point(const RenderArgs& a, int s, int64_t ray, int64_t slot) {
   const int ne = a.nexec ? a.nexec[ray] : a.steps;
-  return (s < ne) ? traj_load<true>(a.traj, R64, slot, s) : load3(a.p_final, ray);
+  return (s < ne) ? traj_load<true>(a.traj, a.steps, slot, s) : load3(a.p_final, ray);
 }
 
 template <class Cfg>
@@ -1979,31 +1998,40 @@ __global__ void __launch_bounds__(256) k_bwd_hard_n(RenderArgs a) {
   auto scene = Cfg::setup(a.scene, rm_smem, store, true);
   const int H = hard_count(a);
   if (H == 0) return;
-  const int64_t R = 64 * wave_tiles(a);
   const int groups = (H + 63) >> 6;
   const int64_t items = (int64_t)groups * a.steps;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  // the next item's list entry and trajectory point (two dependent, scattered loads) are fetched before the
-  // current item's VJP, so their latency hides behind ~600 instructions
+  // Two-deep software pipeline over this wave's items: the list entry (ray, slot, top step) of item + 2 strides and the
+  // point of item + 1 stride are in flight while item's VJP runs -- the point's three candidate loads (step count,
+  // trajectory, final iterate) are issued together and selected afterwards, so nothing waits on a dependent load
+  // (44 % of this kernel's wave-cycles were s_waitcnt with a one-deep prefetch of a three-level chain).
   const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  HardItem cur{0, 0, false, 0, 0};
-  V3 pc = mk3(0.0f, 0.0f, 0.0f);
-  if (first < items) { cur = hard_item(a, first, groups, H); pc = hard_point(a, R, cur.s, cur.ray, cur.slot); }
+  auto entry = [&](int64_t item) {
+    HardItem it{0, 0, false, 0, 0};
+    if (item < items) it = hard_item(a, item, groups, H);
+    return it;
+  };
+  auto point = [&](const HardItem& it) {
+    const int ne = a.nexec ? a.nexec[it.ray] : a.steps;
+    const V3 pt = traj_load<true>(a.traj, a.steps, it.slot, it.s), pf = load3(a.p_final, it.ray);
+    return (it.s < ne) ? pt : pf;
+  };
+  HardItem cur = entry(first), nxt = entry(first + nwaves);
+  V3 pc = point(cur);
   for (int64_t item = first; item < items; item += nwaves) {
-    HardItem nxt{0, 0, false, 0, 0};
-    V3 pn = mk3(0.0f, 0.0f, 0.0f);
-    if (item + nwaves < items) { nxt = hard_item(a, item + nwaves, groups, H); pn = hard_point(a, R, nxt.s, nxt.ray, nxt.slot); }
+    const HardItem nn = entry(item + 2 * nwaves);
+    const V3 pn = point(nxt);
     if (__any(cur.need)) {
       float f;
       const V3 n = scene.vjp_point(pc, 1.0f, &f);
       if (cur.need) {
         const int64_t at = 4 * ((int64_t)cur.s * a.hard_cap + cur.h);
         *reinterpret_cast<float4*>(a.hard_n + at) = make_float4(n.x, n.y, n.z, f);
-        // the point itself, next to its gradient: k_bwd_hard_a copies it into the pair records k_bwd_hard_b works from
+        // the point itself, next to its gradient: k_bwd_hard_b addresses both by the pair code alone
         *reinterpret_cast<float4*>(a.hard_p + at) = make_float4(pc.x, pc.y, pc.z, 0.0f);
       }
     }
-    cur = nxt; pc = pn;
+    cur = nxt; pc = pn; nxt = nn;
   }
 }
 
@@ -2014,7 +2042,6 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
   const bool valid = h0 < H;
   const int h = valid ? h0 : H - 1;
   const int W = a.cam.width, Hh = a.cam.height, rows = a.row_end - a.row_begin;
-  const int64_t R = 64 * wave_tiles(a);
   const int64_t li = a.hard_ray[h], tslot = a.hard_slot[h];
   const int cam = (int)(li / ((int64_t)rows * W));
   const int64_t rem = li - (int64_t)cam * rows * W;
@@ -2064,7 +2091,7 @@ __global__ void k_bwd_hard_a(RenderArgs a) {
       a.hard_pairs[base + k] = ((uint32_t)h << RM_HARD_STEP_BITS) | (uint32_t)(top - (int)k);
   }
   if (want_gv && s >= 0) {     // steps 0..s with lambda frozen: sum_i f(p_i) = (p_{s+1} - p_0).v / |v|^2
-    const V3 dp = hard_point(a, R, s + 1, li, tslot) - traj_load<true>(a.traj, R, tslot, 0);
+    const V3 dp = hard_point(a, s + 1, li, tslot) - traj_load<true>(a.traj, a.steps, tslot, 0);
     const float sumf = ((dp.x * v.x + dp.y * v.y) + dp.z * v.z) / ((v.x * v.x + v.y * v.y) + v.z * v.z);
     gv = gv + sumf * lam;
   }
@@ -2087,24 +2114,31 @@ __global__ void __launch_bounds__(256) RM_HARDB_OCC k_bwd_hard_b(RenderArgs a) {
   const int64_t items = (npairs + 63) >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  auto fetch = [&](int64_t item, float& g, V3& p) {
-    g = 0.0f; p = mk3(0.0f, 0.0f, 0.0f);
+  // two-deep pipeline: the pair code of item + 2 strides and the (upstream, point) of item + 1 stride are in flight
+  // while item's VJP runs
+  auto code_of = [&](int64_t item) -> uint32_t {
     const int64_t k = item * 64 + (threadIdx.x & 63);
-    if (item >= items) return;
-    const uint32_t code = a.hard_pairs[k < npairs ? k : npairs - 1];
+    return (item < items) ? a.hard_pairs[k < npairs ? k : npairs - 1] : 0u;
+  };
+  auto data_of = [&](int64_t item, uint32_t code, float& g, V3& p) {
+    const int64_t k = item * 64 + (threadIdx.x & 63);
     const int h = (int)(code >> RM_HARD_STEP_BITS), st = (int)(code & ((1u << RM_HARD_STEP_BITS) - 1u));
     const int64_t at = (int64_t)st * a.hard_cap + h;
+    g = 0.0f; p = mk3(0.0f, 0.0f, 0.0f);
+    if (item >= items) return;
     const float4 pt = *reinterpret_cast<const float4*>(a.hard_p + 4 * at);
     g = (k < npairs) ? a.hard_g[at] : 0.0f;
     p = mk3(pt.x, pt.y, pt.z);
   };
+  uint32_t code1 = code_of(first + nwaves);
   float gc; V3 pc;
-  fetch(first, gc, pc);
+  data_of(first, code_of(first), gc, pc);
   for (int64_t item = first; item < items; item += nwaves) {
+    const uint32_t code2 = code_of(item + 2 * nwaves);
     float gn; V3 pn;
-    fetch(item + nwaves, gn, pn);                       // before the VJP: its latency hides behind it
+    data_of(item + nwaves, code1, gn, pn);
     scene.vjp(pc, gc);
-    gc = gn; pc = pn;
+    gc = gn; pc = pn; code1 = code2;
   }
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }
