@@ -75,6 +75,7 @@ def parse():
                     help="launcher / collective rehearsal without a GPU: a host stand-in replaces the HIP RenderLoop; the line is marked stub")
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank raises before the first barrier
     ap.add_argument("--graph-leg", action="store_true", help=argparse.SUPPRESS)   # child process of the backward probe
+    ap.add_argument("--interp-leg", action="store_true", help=argparse.SUPPRESS)  # child process: the frame through the LDS interpreter
     return ap.parse_args()
 
 
@@ -437,6 +438,55 @@ def backward_traffic_record(size):
     return pmc.get(f"hbm_bytes_per_step_{size}"), None
 
 
+def interp_leg():
+    """Child process (RM_SPECIALIZE=off): the config-2 frame through the generic LDS interpreter -- what a scene the
+    library has no specialised kernels for renders at until its background build has finished -- and how long that
+    build takes on this box's host (hipcc of the per-scene library into a scratch directory)."""
+    import tempfile
+    from ray_marching_amd.control import RenderLoop
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import make_test_scene2
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    loop = RenderLoop(make_test_scene2(), num_cameras=1, px_width=W, px_height=H_TILE, focal_length=PX * H_TILE,
+                      sensor_width=PX * W, sensor_height=PX * H_TILE, normals_eps=EPS).to(dev)
+    assert not compiled_for(loop.scene).specialised
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
+    t = torch.tensor([[0.0, 0.0, -3.0]], device=dev)
+    ms = frame_rate(loop, q, t, None, frames=10, warm=3)
+    out = {"ms_per_frame": ms, "value": W * H_TILE / ms / 1e3, "unit": "Mrays/s", "build_s": None}
+    try:
+        from ray_marching_amd import specialize
+        specialize.SPEC_DIR = tempfile.mkdtemp(prefix="rm_spec_probe_")
+        t0 = time.perf_counter()
+        specialize.build(compiled_for(loop.scene), force=True)
+        out["build_s"] = time.perf_counter() - t0
+    except Exception as e:      # noqa: BLE001  (no hipcc on this box)
+        log(f"interp leg: build not timed: {e}")
+    print(json.dumps(out), flush=True)
+
+
+def interpreter_record():
+    """`first_frames` field: see interp_leg."""
+    import subprocess
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--interp-leg"], capture_output=True, text=True,
+                           timeout=240, env=dict(os.environ, RM_SPECIALIZE="off"))
+        if r.returncode != 0:
+            log(f"interp leg exited with {r.returncode}: {r.stderr[-300:]}")
+            return None
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        rec["note"] = ("config-2 frame through the generic LDS interpreter (RM_SPECIALIZE=off): what an unknown scene renders at "
+                       "until its per-scene library is built (build_s of hipcc, in a background thread, from the 64th frame on; "
+                       "specialize.ensure(scene) builds it up front)")
+        return rec
+    except Exception as e:      # noqa: BLE001
+        log(f"interp leg failed: {e}")
+        return None
+
+
 def traffic_record(specialised, args):
     """HBM traffic / executed-instruction counters of k_render_fwd from the PMC passes (profiles/collect.sh ->
     profiles/traffic.json) -- only if they were measured on THESE kernel sources and this configuration."""
@@ -540,6 +590,8 @@ def main():
     args = parse()
     if args.graph_leg:
         return graph_leg()
+    if args.interp_leg:
+        return interp_leg()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -816,6 +868,7 @@ def main():
             if not args.skip_config3:
                 out["config3"] = config3_probe(dev)
             out["reference_shape"] = reference_shape_probe(dev)
+            out["first_frames"] = interpreter_record()
         if not args.skip_backward and not config5:
             log("backward probe (config 4 shape) ...")
             out["fwd_bwd"] = backward_probe(dev)
