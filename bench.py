@@ -855,6 +855,8 @@ def main():
                 ms = frame_rate(auto, q, tz, rows, frames=32, warm=48)
                 entry_ = {"camera": [0.0, 0.0, z], "ms_per_frame": ms, "value": rays_per_frame / ms / 1e3, "unit": "Mrays/s",
                           "kernel": kernel_in_use(auto), "fixed_choices": {},
+                          # (frame, pools in use, ms of the probed kernel, ms of the kernel in use) of auto's last decisions
+                          "auto_log": [list(x) for st_ in auto._choice_state.values() for x in st_["log"][-6:]],
                           "note": "the reference's default pose (main.py:46)" if z == 1.0 else "outside the torus, every ray hits"}
                 del auto
                 for name, kw in variants.items():

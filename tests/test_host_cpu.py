@@ -512,3 +512,48 @@ def test_torch_compile_steps_over_the_ctypes_launch():
     scene = torch.compile(make_test_scene2())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         scene(torch.zeros(4, 3))
+
+
+def test_auto_kernel_choice_needs_two_probes_for_a_narrow_loss():
+    """Pools in use: a probe that shows the tile kernel ahead by less than 10 % only raises a doubt; the second one in a
+    row hands over; a clear margin hands over at once; a probe in between that favours the pools clears the doubt."""
+    from ray_marching_amd.control import RenderLoop
+
+    class Ev:
+        def __init__(self, ms):
+            self.ms = ms
+
+        def query(self):
+            return True
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    loop = RenderLoop.__new__(RenderLoop)
+    loop._choice_state, loop.adaptive_order = {}, 4
+    speed = {"tile": 400.0, "regen": 300.0}
+
+    def run(frames):
+        out = []
+        for _ in range(frames):
+            regen, record, sink = loop._choose_kernel_for("k")
+            if sink is not None:
+                sink.append((Ev(0.0), Ev(speed["regen" if regen else "tile"])))
+            out.append(regen)
+        return out
+
+    assert run(12)[-1] is True                         # the pools took over
+    speed.update(tile=290.0)                           # the tile kernel 3 % ahead: first probe = doubt only
+    seq = run(4 * 6)
+    first_tile = seq.index(False, 4) if False in seq[4:] else None
+    st = loop._choice_state["k"]
+    assert st["regen"] is False and first_tile is not None
+    narrow = [e for e in st["log"] if e[1] and e[2] == 290.0]
+    assert len(narrow) == 2, st["log"]                 # two probes of the tile kernel were needed
+    loop._choice_state.clear()
+    speed.update(tile=400.0)
+    run(12)
+    speed.update(tile=250.0)                           # 17 % ahead: at once
+    run(12)
+    st = loop._choice_state["k"]
+    assert st["regen"] is False and len([e for e in st["log"] if e[1] and e[2] == 250.0]) == 1, st["log"]
