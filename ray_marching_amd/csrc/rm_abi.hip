@@ -66,8 +66,8 @@ using G = rm::StaticCfg<RmStaticCode, RM_FWD_REG_PARAMS>;
 using GB = rm::StaticCfg<RmStaticCode, RM_BWD_REG_PARAMS>;   // backward kernels: parameter floats kept in SGPRs up to this many
 // the tile frame kernel of scenes with few parameters keeps them in VGPRs (rm_device.h: RegParams)
 #ifndef RM_FWD_VGPR_PARAM_LIMIT
-#define RM_FWD_VGPR_PARAM_LIMIT 32
-#endif
+#define RM_FWD_VGPR_PARAM_LIMIT 0      // off: see RegParams (rm_device.h) -- it won while one kernel instantiation also carried the
+#endif                                 // recording code (997 v_readlane); with the inference instantiation split off the SGPR form is ahead
 using GF = rm::StaticCfg<RmStaticCode, RM_FWD_REG_PARAMS, (RmStaticCode::n_params + RmStaticCode::n_derived <= RM_FWD_VGPR_PARAM_LIMIT)>;
 // static path: parameter block + (backward) one accumulator row per wave for the block reduction
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
@@ -384,8 +384,11 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     rm::k_render_finish<G><<<gf, LF.block, LF.lds, (hipStream_t)stream>>>(a);
     return launched("k_render_finish");
   }
+  // two instantiations: the plain inference frame, and the one that also records (trajectory / p_final / nexec / normal_u)
+  const bool rec = traj || p_final || nexec || normal_u;
   Launch L;
-  if (int e = pick_launch(rm::k_render_fwd<GF>, *scene, false, tune_block(), &L)) return e;
+  if (int e = rec ? pick_launch(rm::k_render_fwd<GF, true>, *scene, false, tune_block(), &L)
+                  : pick_launch(rm::k_render_fwd<GF, false>, *scene, false, tune_block(), &L)) return e;
   int64_t tiles = (wave_tiles + (L.block >> 6) - 1) / (L.block >> 6);
   int grid = tune_max_blocks() > 0 ? grid_for(tiles, tune_max_blocks()) : (int)tiles;
   if (tune_max_blocks() > 0 && (flags & RM_FLAG_DYNAMIC_TILES) && minmax && !env_set("RM_MAX_BLOCKS")) {
@@ -395,14 +398,17 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     // band); (2) at least ~2 tiles per wave, or the dynamic queues have nothing to balance with (512^2 frame,
     // closed scene 1: 1280 -> 512 blocks, 228 -> 177 us).
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<GF>, L.block, L.lds) == hipSuccess && per_cu > 0) {
+    const hipError_t oe = rec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<GF, true>, L.block, L.lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rm::k_render_fwd<GF, false>, L.block, L.lds);
+    if (oe == hipSuccess && per_cu > 0) {
       const int resident = per_cu * cu_count();
       if (grid > resident) grid = resident;
     }
     const int64_t two_per_wave = (wave_tiles / 2 + (L.block >> 6) - 1) / (L.block >> 6);
     if (grid > two_per_wave) grid = (int)(two_per_wave < 1 ? 1 : two_per_wave);
   }
-  rm::k_render_fwd<GF><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  if (rec) rm::k_render_fwd<GF, true><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
+  else rm::k_render_fwd<GF, false><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_fwd")) return e;
   if (park) {
     Launch LP;

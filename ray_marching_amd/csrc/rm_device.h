@@ -246,12 +246,15 @@ struct LdsParams {
   RM_DEV V3 v3(int i) const { return V3{p[i], p[i + 1], p[i + 2]}; }
 };
 
-// kVgpr: keep the copies in VGPRs instead.  An SGPR source operand makes its consumer a half-rate instruction
-// (profiles/r03_valu_issue_bench.txt: v_sub |v|,s 4.1 cycles against 2.3 for |v|,v) and 106 SGPRs do not hold 25 parameters
-// plus everything else, so the SGPR version spills (v_readlane / v_writelane per use).  Measured on the config-2 tile kernel
-// (profiles/r03_ab_vgpr_params.txt): 127.5 -> 108.5 M executed VALU wave-instructions, 248 -> 235 us at (0,0,-3) and
-// 493 -> 463 us at (0,0,1) under rocprofv3; but +22 VGPRs per kernel: the ray pools got 29 % slower and the backward
-// kernels lose their last wave of occupancy, so only k_render_fwd of scenes with few parameters takes it.
+// kVgpr: keep the copies in VGPRs instead (A/B knob, RM_FWD_VGPR_PARAM_LIMIT; off).  An SGPR source operand makes its
+// consumer a half-rate instruction (profiles/r03_valu_issue_bench.txt: v_sub |v|,s 4.1 cycles against 2.3 for |v|,v), and
+// when the SGPRs are oversubscribed every use of a spilled one is a v_readlane.  Round 3, same-box A/Bs of the config-2
+// tile kernel (profiles/r03_ab_vgpr_params.txt, r03_ab_vgpr_final.txt, r03_ab_vs_round2.txt): while ONE instantiation
+// of k_render_fwd served inference and recording frames, the SGPR form carried 997 v_readlane and VGPR copies won by 7 %
+// (238 -> 221 us; 127.5 -> 108.5 M executed VALU wave-instructions); once the inference instantiation was split off
+// (357 v_readlane) the SGPR form is the faster one: 0.205 ms against 0.215 ms with VGPR copies (round-2 tree on that box:
+// 0.208).  VGPR copies also cost 22 VGPRs per kernel: the ray pools got 29 % slower with them, the backward kernels
+// lose their last wave of occupancy.
 template <int N, bool kVgpr = false>
 struct RegParams {
   float v[N > 0 ? N : 1];
@@ -703,6 +706,7 @@ struct Ins {
 // Interpreter; instruction words are wave-uniform (scalar loads when `code` points at global memory).
 struct RuntimeProgram {
   static constexpr int kTracked = 0;     // the interpreter always runs the full cull test
+  static constexpr bool kNeedsFullWave = true;   // may contain CULL_LSE (wave-wide DPP reductions: every lane active)
   const int4* code;
   int n;
   template <class S, class PT>
@@ -766,6 +770,12 @@ struct StaticProgram {
     return k;
   }
   static constexpr int kTracked = count_tracked();
+  static constexpr bool has_cull_lse() {
+    for (int i = 0; i < Code::n; ++i)
+      if (Code::code[i].op == RM_OP_CULL_LSE) return true;
+    return false;
+  }
+  static constexpr bool kNeedsFullWave = has_cull_lse();   // lse_cull_mask's DPP reductions need every lane of the wave active
   // does the smooth union that ends at `pc` carry a bound table (exact culling of its children, RM_OP_CULL_LSE)?
   static constexpr bool smooth_culled(int pc) {
     int depth = 0;

@@ -1029,7 +1029,9 @@ struct MinMaxAcc {
 };
 
 // distance, normals / Laplacian, shader, stores (control.py:244-257)
-template <class SceneT>
+// kAux = false: a frame that asked for none of the per-ray outputs p_final / nexec / normal_u (plain inference): the stores
+// and their kernel arguments are compiled out
+template <class SceneT, bool kAux = true>
 RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T, const TileRays& r, V3 p, int nexec,
                         MinMaxAcc& mm, bool store_p = true) {
   const int mode = a.mode;
@@ -1039,8 +1041,10 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   if (mode == RM_MODE_PROXIMITY || mode == RM_MODE_LAPLACIAN) dist = scene.eval(p);
   V3 n = mk3(0.0f, 0.0f, 0.0f), u = n;
   float lap = 0.0f;
-  if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap, &u);
-  if (a.normal_u && r.live) store3(a.normal_u, r.li, u);
+  if (mode == RM_MODE_LAMBERTIAN || mode >= RM_MODE_NORMAL) normals_forward(scene, T, p, dist, n, lap, kAux ? &u : nullptr);
+  if constexpr (kAux) {
+    if (a.normal_u && r.live) store3(a.normal_u, r.li, u);
+  }
   ShadeIn si;
   si.o = r.o; si.v = r.v; si.p = p; si.n = n; si.lap = lap; si.dist = dist;
   si.qw = r.ps.w; si.qv = r.ps.qv;
@@ -1054,8 +1058,10 @@ RM_DEV void finish_tile(const RenderArgs& a, const SceneT& scene, const Tetra& T
   if (r.live) {
     if (global) store3(a.first_pass, r.li, out);          // rm_shade_finish normalises into `image`
     else store_shaded(a.image, a.image_dtype, r.li, sh, a.cmap, a.cmap_dtype, a.cam.dtype);
-    if (store_p && a.p_final) store3(a.p_final, r.li, p);
-    if (a.nexec) a.nexec[r.li] = nexec;
+    if constexpr (kAux) {
+      if (store_p && a.p_final) store3(a.p_final, r.li, p);
+      if (a.nexec) a.nexec[r.li] = nexec;
+    }
     if (mode == RM_MODE_DISTANCE || mode == RM_MODE_PROXIMITY) {
       mm.saw_nan |= (out.x != out.x);
       mm.lo = fminf(mm.lo, out.x); mm.hi = fmaxf(mm.hi, out.x);
@@ -1098,7 +1104,10 @@ struct ParkToList {
   }
 };
 
-template <class Cfg>
+// kRecord = false: the plain inference frame (no trajectory, no per-ray outputs): the recording code and its live kernel
+// arguments are compiled out of the march loop.  (Sharing one instantiation cost the headline frame 6 % in round 3:
+// 208 -> 221 us on one box, 687 -> 997 v_readlane in the kernel from the extra SGPR pressure.)
+template <class Cfg, bool kRecord = true>
 __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
   typename Cfg::Store store;
   auto scene = Cfg::setup(a.scene, rm_smem, store);
@@ -1113,12 +1122,13 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     int nexec;
     bool parked;
     // (a recorded trajectory is indexed by the wave tile's slot, not by the pixel: traj_store<true>)
-    V3 p = march<decltype(scene), ParkToList, true>(scene, r.o, r.v, a.steps, early, a.traj, a.steps,
-                                                    a.traj ? tile * 64 + (threadIdx.x & 63) : r.li, r.live, nexec,
+    float* const traj = kRecord ? a.traj : nullptr;
+    V3 p = march<decltype(scene), ParkToList, true>(scene, r.o, r.v, a.steps, early, traj, a.steps,
+                                                    traj ? tile * 64 + (threadIdx.x & 63) : r.li, r.live, nexec,
                                                     ParkToList{a, r.li}, &parked);
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tile] = nexec;     // nexec is wave-uniform
     r.live = r.live && !parked;                 // a parked ray's pixel is written by k_render_parked
-    finish_tile(a, scene, T, r, p, nexec, mm);
+    finish_tile<decltype(scene), kRecord>(a, scene, T, r, p, nexec, mm);
   }
   if (a.minmax && (a.mode == RM_MODE_DISTANCE || a.mode == RM_MODE_PROXIMITY || a.mode == RM_MODE_LAPLACIAN))
     fold_minmax(a.minmax, mm.lo, mm.hi, mm.saw_nan);
@@ -1313,36 +1323,55 @@ __global__ void __launch_bounds__(256) k_march_regen(RenderArgs a) {
     if (__any(act && k >= RM_PRIO_REGEN)) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
 #endif
-    const unsigned long long actm = __ballot(act);
-    if (actm) {
-      // The scene is evaluated with EVERY lane of the wave active (the wave-wide reductions of lse_cull_mask need
-      // that): a lane without a marching ray shadows the first active lane's ray -- the same point, hence the same
-      // votes in every wave-uniform cull test and no influence on the bounds -- and throws the result away.
-      const int src = __builtin_ctzll(actm);
-      auto from = [&](float x) {
-        return act ? x : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
-      };
-      V3 pe = mk3(from(p.x), from(p.y), from(p.z));
-      const V3 ve = mk3(from(v.x), from(v.y), from(v.z));
-      const float vne = from(vn);
-      float movee = from(move);
-      V3 prev = pe;
-      for (int j = 0; j < 4; ++j) {
-        const float f = scene.eval_near(pe, ((it + j) & 15) ? movee : __builtin_nanf(""));
-        movee = __builtin_fmaf(fabsf(f), vne, 4e-6f);
-        prev = pe;
-        pe = step_point(pe, ve, f);
-      }
+    if constexpr (!decltype(scene.prog)::kNeedsFullWave) {
       if (act) {
-        p = pe; move = movee;
+        V3 prev = p;
+        for (int j = 0; j < 4; ++j) {
+          const float f = scene.eval_near(p, ((it + j) & 15) ? move : __builtin_nanf(""));
+          move = __builtin_fmaf(fabsf(f), vn, 4e-6f);
+          prev = p;
+          p = step_point(p, v, f);
+        }
         k += 4;
         if (lambda == 0) {
           const int found = same_bits(p, prev) ? 1 : (same_bits(p, snap) ? (k - snap_step) : 0);
           if (found) { lambda = found; stop = k + (S - k) % found; }
         }
         if (k == next_snap) { snap = p; snap_step = k; next_snap <<= 1; }
-      } else {
-        move = __builtin_nanf("");      // the tracked cull bounds now describe the shadowed ray, not this lane's next one
+      }
+    } else {
+      // Programs with CULL_LSE evaluate the scene with EVERY lane of the wave active (the wave-wide reductions of
+      // lse_cull_mask need that): a lane without a marching ray shadows the first active lane's ray -- the same point,
+      // hence the same votes in every wave-uniform cull test and no influence on the bounds -- and throws the result
+      // away.  (Costs the pools ~5 % -- 0.311 -> 0.327 ms at (0,0,1) when every program paid it -- so only those do.)
+      const unsigned long long actm = __ballot(act);
+      if (actm) {
+        const int src = __builtin_ctzll(actm);
+        auto from = [&](float x) {
+          return act ? x : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+        };
+        V3 pe = mk3(from(p.x), from(p.y), from(p.z));
+        const V3 ve = mk3(from(v.x), from(v.y), from(v.z));
+        const float vne = from(vn);
+        float movee = from(move);
+        V3 prev = pe;
+        for (int j = 0; j < 4; ++j) {
+          const float f = scene.eval_near(pe, ((it + j) & 15) ? movee : __builtin_nanf(""));
+          movee = __builtin_fmaf(fabsf(f), vne, 4e-6f);
+          prev = pe;
+          pe = step_point(pe, ve, f);
+        }
+        if (act) {
+          p = pe; move = movee;
+          k += 4;
+          if (lambda == 0) {
+            const int found = same_bits(p, prev) ? 1 : (same_bits(p, snap) ? (k - snap_step) : 0);
+            if (found) { lambda = found; stop = k + (S - k) % found; }
+          }
+          if (k == next_snap) { snap = p; snap_step = k; next_snap <<= 1; }
+        } else {
+          move = __builtin_nanf("");      // the tracked cull bounds now describe the shadowed ray, not this lane's next one
+        }
       }
     }
     it += 4;
