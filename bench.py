@@ -871,7 +871,7 @@ def main():
                 out["config3"] = config3_probe(dev)
             out["reference_shape"] = reference_shape_probe(dev)
             out["first_frames"] = interpreter_record()
-        if not args.skip_backward and not config5:
+        if world == 1 and not args.skip_backward and not config5:      # (single-GPU legs: the other ranks would only wait for rank 0)
             log("backward probe (config 4 shape) ...")
             out["fwd_bwd"] = backward_probe(dev)
             log(f"backward probe: {out['fwd_bwd']}")
