@@ -557,3 +557,34 @@ def test_auto_kernel_choice_needs_two_probes_for_a_narrow_loss():
     run(12)
     st = loop._choice_state["k"]
     assert st["regen"] is False and len([e for e in st["log"] if e[1] and e[2] == 250.0]) == 1, st["log"]
+
+
+def test_auto_kernel_choice_looks_again_after_a_cold_first_probe():
+    """The very first probe of the pools runs them without a dealing order and with first-use allocations; when it loses,
+    the pools are looked at again in the NEXT cycle (then every fourth), so a scene where they are the faster kernel
+    is not rendered 64 frames on the slower one."""
+    from ray_marching_amd.control import RenderLoop
+
+    class Ev:
+        def __init__(self, ms):
+            self.ms = ms
+
+        def query(self):
+            return True
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    loop = RenderLoop.__new__(RenderLoop)
+    loop._choice_state, loop.adaptive_order = {}, 4
+    pools_ms = iter([505.0] + [320.0] * 100)          # cold, then what they really take
+    probes, in_use = [], []
+    for frame in range(4 * 8):
+        regen, record, sink = loop._choose_kernel_for("k")
+        if sink is not None:
+            sink.append((Ev(0.0), Ev(next(pools_ms) if regen else 420.0)))
+        if record:
+            probes.append(frame)
+        in_use.append(regen)
+    assert probes[:2] == [0, 4], probes               # second look one cycle later, not four
+    assert all(in_use[7:]), in_use                    # ... after which the pools are in use
