@@ -32,7 +32,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kMaxBlocks = 2048;        // persistent grid cap: 256 CUs x 8 blocks
 constexpr int kMaxBlocksBwd = 2048;     // rows of per-block partial sums a backward kernel may write
 constexpr int kHardBlocksB = 2048;      // + rows of k_bwd_hard_b (deferred rays)
-constexpr int kPartialRows = 2 * (kMaxBlocksBwd + kHardBlocksB);      // the specialised kernels write one row per WAVE (blocks of 128)
+constexpr int kPartialRows = kMaxBlocksBwd + kHardBlocksB;
 constexpr size_t kLdsDefault = 64 * 1024;
 constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
 
@@ -93,9 +93,6 @@ size_t lds_bytes(const RmScene& sc, int block, bool backward) {
   return 4 * (pb + 4 * (size_t)sc.n_instr + per_thread * (block + 1));
 }
 #endif
-
-// rows of per-block (interpreter) or per-wave (specialised kernels: no barrier at the end) partial sums of a backward launch
-int partial_rows(int grid, int block) { return GB::kStatic ? grid * (block >> 6) : grid; }
 
 template <class K>
 int pick_launch(K kernel, const RmScene& sc, bool backward, int max_block, Launch* out) {
@@ -216,7 +213,7 @@ int rm_sdf_backward(const RmScene* scene, const float* points, const float* grad
   int grid = grid_for((n + L.block - 1) / L.block, 1024);
   rm::k_sdf_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, points, grad_dist, grad_points, partials, n);
   if (int e = launched("k_sdf_bwd")) return e;
-  return reduce_partials(*scene, partials, partial_rows(grid, L.block), grad_params, (hipStream_t)stream);
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
 #endif
 }
 
@@ -248,7 +245,7 @@ int rm_march_backward(const RmScene* scene, const float* dirs, const float* traj
   rm::k_march_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, dirs, traj, nexec, grad_out, grad_pos, grad_dirs,
                                                                    partials, n, steps);
   if (int e = launched("k_march_bwd")) return e;
-  return reduce_partials(*scene, partials, partial_rows(grid, L.block), grad_params, (hipStream_t)stream);
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
 #endif
 }
 
@@ -279,7 +276,7 @@ int rm_normals_backward(const RmScene* scene, const RmTetra* tetra, const float*
   rm::k_normals_bwd<GB><<<grid, L.block, L.lds, (hipStream_t)stream>>>(*scene, *tetra, coords, grad_normals, grad_lap,
                                                                      grad_coords, partials, n);
   if (int e = launched("k_normals_bwd")) return e;
-  return reduce_partials(*scene, partials, partial_rows(grid, L.block), grad_params, (hipStream_t)stream);
+  return reduce_partials(*scene, partials, grid, grad_params, (hipStream_t)stream);
 #endif
 }
 
@@ -609,7 +606,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
   else if (kind == 3) rm::k_render_bwd<GB, 3><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   else rm::k_render_bwd<GB, 0><<<grid, L.block, L.lds, (hipStream_t)stream>>>(a);
   if (int e = launched("k_render_bwd")) return e;
-  int rows = partial_rows(grid, L.block);
+  int rows = grid;
   if (defer) {
     Launch LN, LB;
     if (int e = pick_launch(rm::k_bwd_hard_n<GB>, *scene, true, 128, &LN)) return e;
@@ -622,7 +619,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
     b.partials = partials + (size_t)rows * (scene->n_params + scene->n_grad_derived);     // its rows follow k_render_bwd's
     rm::k_bwd_hard_b<GB><<<tune_hardb_blocks(), LB.block, LB.lds, (hipStream_t)stream>>>(b);
     if (int e = launched("k_bwd_hard_b")) return e;
-    rows += partial_rows(tune_hardb_blocks(), LB.block);
+    rows += tune_hardb_blocks();
   }
   return reduce_partials(*scene, partials, rows, grad_params, (hipStream_t)stream);
 #endif

@@ -140,18 +140,20 @@ RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float*
       partials[(int64_t)blockIdx.x * n_acc + i] = sum;
     }
   } else {
-    // registers: butterfly over the wave, ONE ROW PER WAVE -- partials[(block * waves + wave)][n_acc].  No barrier: a
-    // block-level sum made the wave of a block that finished its tiles first wait at __syncthreads() for the other
-    // one, up to a whole tile's time (the backward kernels run two tiles per wave; their waves spent 54-66 % of
-    // their cycles waiting, profiles/r03_stalls.txt).  k_reduce_partials adds the rows up in a fixed order.
-    (void)smem_scratch;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    float* row = partials + ((int64_t)blockIdx.x * nw + wave) * n_acc;
+    // registers: butterfly over the wave, then waves through LDS scratch
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < Cfg::kAcc; ++i) {
       float v = sc.st->ld(sc.acc0 + i);
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) row[i] = v;
+      if (lane == 0) smem_scratch[wave * n_acc + i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
+      float sum = 0.0f;
+      for (int w = 0; w < nw; ++w) sum += smem_scratch[w * n_acc + i];
+      partials[(int64_t)blockIdx.x * n_acc + i] = sum;
     }
   }
 }
