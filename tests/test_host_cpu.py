@@ -588,3 +588,27 @@ def test_auto_kernel_choice_looks_again_after_a_cold_first_probe():
         in_use.append(regen)
     assert probes[:2] == [0, 4], probes               # second look one cycle later, not four
     assert all(r for f, r in enumerate(in_use) if f >= 7 and f not in probes), in_use     # ... after which the pools are in use (probe frames run the tile kernel)
+
+
+def test_abi_header_is_plain_c():
+    """include/rm_abi.h is the boundary a maintainer binds from C, cgo, JNI or ctypes: it must compile as C99 and as
+    C++11 on its own, without HIP or torch headers, and a C program must be able to name every entry point."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    header = os.path.join(ROOT, "include", "rm_abi.h")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        r = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Werror", "-x", lang, header], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "use.c")
+        with open(src, "w") as f:
+            f.write('#include "rm_abi.h"\nint main(void) {\n  void* p[] = {' +
+                    ", ".join(f"(void*){name}" for name in declared_functions()) +
+                    "};\n  RmScene s; RmCamera c; RmTetra t; RmParamRef r;\n  (void)s; (void)c; (void)t; (void)r;\n"
+                    "  return (int)(sizeof(p) / sizeof(p[0])) + RM_ABI_VERSION + RM_OP_CULL_LSE + RM_DTYPE_RGBA_F32 + RM_WORK_WORDS > 0 ? 0 : 1;\n}\n")
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", os.path.join(tmp, "use.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
