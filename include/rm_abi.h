@@ -72,13 +72,17 @@ enum {
   RM_OP_FOLD_MIN = 10,     /* aux0 = tape slot; aux1 = distance back to its CULL_MIN (0 = none) */
   RM_OP_UNION_END = 11,    /* aux0 = first tape slot, aux1 = child count */
   RM_OP_SMOOTH_BEGIN = 12, /* P: blend_k (read only when aux0 != 0); aux0 = derived offset of the children's bound table, 8 floats per
-                              child in slot order (0 = no culling inside this smooth union), aux1 = first tape slot << 8 | child count
-                              (<= 64 children, slots < 64)    transformations.py:67-71 */
+                              child in slot order, 16-byte aligned, written by the kernels at staging time (0 = none); aux1 =
+                              (children are culled: RM_OP_CULL_LSE) << 16 | first tape slot << 8 | child count (<= 64 children,
+                              slots < 64)    transformations.py:67-71 */
   RM_OP_FOLD_LSE = 13,     /* P: blend_k; aux0 = tape slot; aux1 = distance back to its CULL_LSE (0 = none) */
   RM_OP_SMOOTH_END = 14,   /* P: blend_k; aux0 = first tape slot, aux1 = child count; slot aux0+aux1 holds the logsumexp */
   RM_OP_ROUND = 15,        /* P: rounding                   transformations.py:117-118 */
   RM_OP_ONION = 16,        /* P: radius; aux0 = tape slot   transformations.py:131-132 */
-  RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: aux0 = derived offset of its bound, 5 floats
+  RM_OP_CULL_MIN = 17,     /* before a child of an SDFUnion: `param offset` field = 1 when the child is a smooth union whose SMOOTH_BEGIN
+                              (the next instruction) carries a bound table: the union is then also skipped when the minimum of
+                              its children's own lower bounds minus log(n) / blend_k cannot lower the running minimum, else 0;
+                              aux0 = derived offset of its bound, 5 floats
                               {cx,cy,cz,K,slope} written by the kernels at staging time; aux1 = (n << 8) | slot, n = instructions up to and including the
                               child's FOLD_MIN (whose aux1 = n).  Skips the child when it cannot lower the
                               running minimum for any ray of the wave (exact) */

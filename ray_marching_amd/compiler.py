@@ -205,6 +205,10 @@ class _Emitter:
         # and the wave-wide test costs more than they save); RM_CULL_LSE_MIN: children from which on it is emitted
         self.cull_lse = os.environ.get("RM_CULL_LSE", "0") == "1"
         self.cull_lse_min = int(os.environ.get("RM_CULL_LSE_MIN", _CULL_LSE_MIN_CHILDREN))
+        # RM_CULL_UNION_TABLE=0: a smooth union that is a cullable child of a min-union is tested with ONE bounding sphere only
+        # (default: also with the minimum of its children's own bounds, rm_device.h: cull_union_children)
+        self.cull_union_table = os.environ.get("RM_CULL_UNION_TABLE", "1") != "0"
+        self.want_table = False        # set by the parent union for the child it emits next
 
     def off(self, *params):
         """Offset of the first parameter; the rest must follow contiguously."""
@@ -268,12 +272,17 @@ def _emit(node, em: _Emitter, n_params: int):
         # The test runs once per evaluation, one child per lane, from a table of bounds (8 floats per child, 16-byte
         # aligned, filled in on the device); the skip bits live at the children's tape slots, hence slots < 64.
         lse_table = 0
-        if smooth and em.cull and em.cull_lse and em.cull_lse_min <= len(kids) <= 64 and base + len(kids) <= 64:
+        want_table, em.want_table = em.want_table, False
+        cull_children = smooth and em.cull and em.cull_lse and em.cull_lse_min <= len(kids)
+        want_table = want_table and em.cull_lse_min <= len(kids)        # ~45 instructions per test: not for a handful of children
+        if smooth and em.cull and (cull_children or want_table) and len(kids) <= 64 and base + len(kids) <= 64:
             em.n_derived += (-(n_params + em.n_derived)) % 4
             lse_table = n_params + em.n_derived
             em.n_derived += 8 * len(kids)
+        cull_children = cull_children and bool(lse_table)
         if smooth:
-            em.ins(A.OP_SMOOTH_BEGIN, koff if lse_table else 0, lse_table, ((base << 8) | len(kids)) if lse_table else 0)
+            em.ins(A.OP_SMOOTH_BEGIN, koff if lse_table else 0, lse_table,
+                   ((int(cull_children) << 16) | (base << 8) | len(kids)) if lse_table else 0)
         else:
             em.ins(A.OP_UNION_BEGIN)
         em.push(_STACK_SMOOTH if smooth else _STACK_UNION)
@@ -295,13 +304,18 @@ def _emit(node, em: _Emitter, n_params: int):
                 em.ins(A.OP_CULL_MIN, 0, n_params + em.n_derived, 0)      # aux1 patched below
                 em.n_derived += 5      # {cx, cy, cz, K, slope}, filled in on the device
             lse_at = None
-            if lse_table:
+            if cull_children:
                 lse_at = len(em.code)
                 em.ins(A.OP_CULL_LSE, lse_table + 8 * i, base + i, 0)           # aux1 patched below
+            if cull_at is not None and em.cull_union_table and getattr(child, "_rm_kind", None) == "smooth_union":
+                em.want_table = True           # the child emits a bound table on its SMOOTH_BEGIN when its slots allow
             _emit(child, em, n_params)
+            em.want_table = False
             if cull_at is not None:
                 skip = len(em.code) - cull_at
-                em.code[cull_at] = (A.OP_CULL_MIN, 0, em.code[cull_at][2], (skip << 8) | (base + i))
+                nxt = em.code[cull_at + 1]
+                by_children = int(nxt[0] == A.OP_SMOOTH_BEGIN and nxt[2] != 0)     # also tested with the children's own bounds
+                em.code[cull_at] = (A.OP_CULL_MIN, by_children, em.code[cull_at][2], (skip << 8) | (base + i))
                 em.ins(A.OP_FOLD_MIN, 0, base + i, skip)
             elif lse_at is not None:
                 skip = len(em.code) - lse_at

@@ -699,8 +699,9 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_UNION_BEGIN: depth_f += 1; depth_b += 2; break;
       case RM_OP_SMOOTH_BEGIN:
         depth_b += 2;
-        if (a0 != 0) {     // bound table of an exactly culled smooth union
-          const int base = a1 >> 8, n = a1 & 255;
+        if (a0 != 0) {     // bound table of a smooth union (for the culling of its children and / or of the union as a whole)
+          const int base = (a1 >> 8) & 255, n = a1 & 255;
+          if ((a1 >> 16) & ~1) return fail(RM_E_PROGRAM, "instr %d: SMOOTH_BEGIN flags", i);
           if (off < 0 || off >= n_params) return fail(RM_E_PROGRAM, "instr %d: SMOOTH_BEGIN blend_k out of range", i);
           if (n < 1 || n > 64 || base < 0 || base + n > 64 || base + n > n_slots || a0 < n_params || (a0 & 3) ||
               a0 + 8 * n > n_params + n_derived)
@@ -737,6 +738,8 @@ int rm_validate_program(const int32_t* host_program, int32_t n_instr, int32_t n_
       case RM_OP_CULL_MIN: {
         const int skip = a1 >> 8, slot = a1 & 255;
         if (a0 < n_params || a0 + 5 > n_params + n_derived) return fail(RM_E_PROGRAM, "instr %d: bound out of range", i);
+        if (off != 0 && (off != 1 || i + 1 >= n_instr || host_program[4 * (i + 1)] != RM_OP_SMOOTH_BEGIN || host_program[4 * (i + 1) + 2] == 0))
+          return fail(RM_E_PROGRAM, "instr %d: CULL_MIN by children needs a SMOOTH_BEGIN with a bound table next", i);
         if (skip < 2 || i + skip >= n_instr || slot >= 64 || slot >= n_slots ||
             host_program[4 * (i + skip)] != RM_OP_FOLD_MIN || host_program[4 * (i + skip) + 2] != slot ||
             host_program[4 * (i + skip) + 3] != skip)

@@ -384,6 +384,37 @@ RM_DEV unsigned long long lse_cull_mask(const S& s, const PT& P, int koff, int t
   return __ballot(cull);
 }
 
+// Whole-smooth-union culling from the SAME table (RM_OP_CULL_MIN in front of a smooth union, `param offset` field = 1):
+//     -lse(-k d) / k  >=  min_j d_j - log(n) / k  >=  min_j lb_j - log(n) / k,
+// with the per-child lower bounds lb_j evaluated -- one child per lane -- on the ball that holds the points of all 64
+// rays.  ONE sphere around all the children (cull_min_test) is loose for a cluster that fills the room: in the config-5
+// scene it lets 21.5 % of the evaluations skip the union, the per-child minimum 30.1 % (profiles/r03_lse_cull_rate.txt).
+// Tried only when the one-sphere test has failed.  An unbounded child (K_lb = NaN) makes the minimum -inf.
+template <class S, class PT>
+RM_DEV bool cull_union_children(const S& s, const PT& P, int koff, int table, int base, int n) {
+  const int lane = threadIdx.x & 63;
+  const float k = P[koff];
+  const V3 c0 = mk3(uniform_f(s.p.x), uniform_f(s.p.y), uniform_f(s.p.z));
+  const V3 d0 = s.p - c0;
+  const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(d0.z, d0.z, __builtin_fmaf(d0.y, d0.y, d0.x * d0.x)));
+  // a lane whose point is NaN keeps rho finite (fmaxf ignores it) -- and fails the final comparison through its NaN acc
+  const float rho = __builtin_fmaf(wave_reduce<true>(r), 1.0001f, 1e-6f * ((fabsf(c0.x) + fabsf(c0.y)) + fabsf(c0.z)) + 1e-6f);
+  const int j = lane - base;
+  const bool mine = (j >= 0) & (j < n);
+  const float4* e = reinterpret_cast<const float4*>(s.lds + table + 8 * (mine ? j : 0));
+  const float4 ea = e[0], eb = e[1];
+  const V3 dc = c0 - mk3(ea.x, ea.y, ea.z);
+  const float t = __builtin_amdgcn_sqrtf(__builtin_fmaf(dc.z, dc.z, __builtin_fmaf(dc.y, dc.y, dc.x * dc.x)));
+  float lb = __builtin_fmaf(ea.w, __builtin_fmaxf(__builtin_fmaf(t, 0.99999f, -rho), 0.0f), -eb.x);
+  lb = (lb == lb) ? lb : -__builtin_inff();                      // unbounded child: no bound at all
+  lb = mine ? lb : __builtin_inff();
+  const float lbmin = wave_reduce<false>(lb);
+  // log(n) / k with a relative margin, and the absolute one of cull_min_test on top of the children's own (folded into K_lb)
+  const float slack = __builtin_fmaf(__builtin_amdgcn_logf((float)n) * 0.693147180559945309417f, 1.001f / k, 1e-4f);
+  const float bound = lbmin - slack;
+  return (k > 0.0f) && __all(bound >= s.acc);                    // NaN anywhere: false
+}
+
 template <class S, class PT>
 RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
   switch (op) {
@@ -440,8 +471,8 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       s.d = s.acc;
       s.sp -= 1; s.acc = s.st->ld(s.sp);
       break;
-    case RM_OP_SMOOTH_BEGIN:   // a0 = bound table (0: none), a1 = first tape slot << 8 | children
-      if (a0 > 0) s.culled |= lse_cull_mask(s, P, off, a0, a1 >> 8, a1 & 255);
+    case RM_OP_SMOOTH_BEGIN:   // a0 = bound table (0: none), a1 = culling of the children on << 16 | first tape slot << 8 | children
+      if (a0 > 0 && (a1 >> 16)) s.culled |= lse_cull_mask(s, P, off, a0, (a1 >> 8) & 255, a1 & 255);
       break;
     case RM_OP_FOLD_LSE:  // children are kept on the tape; the reduction is two-pass like torch.logsumexp
       s.st->st(s.tape0 + a0, s.d);
@@ -715,7 +746,12 @@ struct RuntimeProgram {
       int4 w = code[pc];
       const int op = uniform_i(w.x), off = uniform_i(w.y), a0 = uniform_i(w.z), a1 = uniform_i(w.w);
       if (op == RM_OP_CULL_MIN) {            // a1 = (instructions up to and including the child's FOLD) << 8 | slot
-        if (cull_min_test(s, P, a0)) {
+        bool cull = cull_min_test(s, P, a0);
+        if (!cull && off != 0) {             // the child is a smooth union with a bound table (its SMOOTH_BEGIN follows)
+          const int4 sb = code[pc + 1];
+          cull = cull_union_children(s, P, uniform_i(sb.y), uniform_i(sb.z), (uniform_i(sb.w) >> 8) & 255, uniform_i(sb.w) & 255);
+        }
+        if (cull) {
           const int slot = a1 & 255;
           if (s.record) { s.st->st(s.tape0 + slot, __builtin_inff()); s.culled |= 1ull << slot; }
           pc += a1 >> 8;
@@ -770,18 +806,18 @@ struct StaticProgram {
     return k;
   }
   static constexpr int kTracked = count_tracked();
-  static constexpr bool has_cull_lse() {
+  static constexpr bool has_wave_reductions() {
     for (int i = 0; i < Code::n; ++i)
-      if (Code::code[i].op == RM_OP_CULL_LSE) return true;
+      if (Code::code[i].op == RM_OP_CULL_LSE || (Code::code[i].op == RM_OP_CULL_MIN && Code::code[i].off != 0)) return true;
     return false;
   }
-  static constexpr bool kNeedsFullWave = has_cull_lse();   // lse_cull_mask's DPP reductions need every lane of the wave active
+  static constexpr bool kNeedsFullWave = has_wave_reductions();   // the DPP reductions of the table tests need every lane of the wave active
   // does the smooth union that ends at `pc` carry a bound table (exact culling of its children, RM_OP_CULL_LSE)?
   static constexpr bool smooth_culled(int pc) {
     int depth = 0;
     for (int i = pc; i >= 0; --i) {
       if (Code::code[i].op == RM_OP_SMOOTH_END) ++depth;
-      if (Code::code[i].op == RM_OP_SMOOTH_BEGIN && --depth == 0) return Code::code[i].a0 != 0;
+      if (Code::code[i].op == RM_OP_SMOOTH_BEGIN && --depth == 0) return Code::code[i].a0 != 0 && (Code::code[i].a1 >> 16) != 0;
     }
     return false;
   }
@@ -795,6 +831,10 @@ struct StaticProgram {
         constexpr int T = tracked_site(PC);
         bool cull;
         if constexpr (T >= 0) cull = cull_min_tracked<T>(s, P, i.a0); else cull = cull_min_test(s, P, i.a0);
+        if constexpr (i.off != 0) {           // the child is a smooth union with a bound table (its SMOOTH_BEGIN follows)
+          constexpr Ins sb = Code::code[PC + 1];
+          if (!cull) cull = cull_union_children(s, P, sb.off, sb.a0, (sb.a1 >> 8) & 255, sb.a1 & 255);
+        }
         if (cull) {
           if (s.record) { s.st->st(s.tape0 + slot, __builtin_inff()); s.culled |= 1ull << slot; }
         } else {
@@ -1062,21 +1102,34 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
   if (threadIdx.x == 0) {     // bounding spheres: few, tiny, one after the other on one thread
     for (int pc = 0; pc < n_instr; ++pc) {
       const int4 w = ins(pc);
-      if (w.x == RM_OP_CULL_LSE) {
-        // bound table entry of a smooth-union child (lse_cull_mask): {cx, cy, cz, slope_lb, K_lb, slope_ub, K_ub, 0},
-        // the lower bound with the margins of CULL_MIN, the upper one with the same ones on the other side
-        float b[7];
-        subtree_bound(ins, s_params, pc + 1, pc + w.w, b, s_bound_stack);          // child without its FOLD_LSE
-        float* out = s_params + w.y;
-        const float c1 = (fabsf(b[0]) + fabsf(b[1])) + fabsf(b[2]);
-        const float Kl = ((b[3] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
-        const float Ku = ((b[5] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
-        out[0] = b[0]; out[1] = b[1]; out[2] = b[2];
-        out[3] = b[4] - 2e-4f;
-        out[4] = Kl < __builtin_inff() ? Kl : __builtin_nanf("");
-        out[5] = b[6] + 2e-4f;
-        out[6] = Ku < __builtin_inff() ? Ku : __builtin_inff();
-        out[7] = 0.0f;
+      if (w.x == RM_OP_SMOOTH_BEGIN && w.z > 0) {
+        // bound table of a smooth union, one entry per child in slot order: {cx, cy, cz, slope_lb, K_lb, slope_ub, K_ub, 0},
+        // the lower bound with the margins of CULL_MIN, the upper one with the same ones on the other side.  Children are
+        // the instruction ranges between the FOLD_LSEs of this union's own level (a CULL_LSE in front is skipped).
+        int q = pc + 1;
+        for (int j = 0; j < (w.w & 255); ++j) {
+          if (ins(q).x == RM_OP_CULL_LSE) ++q;
+          int end = q, depth = 0;
+          for (;; ++end) {
+            const int op = ins(end).x;
+            if (op == RM_OP_UNION_BEGIN || op == RM_OP_SMOOTH_BEGIN) ++depth;
+            else if (op == RM_OP_UNION_END || op == RM_OP_SMOOTH_END) --depth;
+            else if (op == RM_OP_FOLD_LSE && depth == 0) break;
+          }
+          float b[7];
+          subtree_bound(ins, s_params, q, end, b, s_bound_stack);
+          float* out = s_params + w.z + 8 * j;
+          const float c1 = (fabsf(b[0]) + fabsf(b[1])) + fabsf(b[2]);
+          const float Kl = ((b[3] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
+          const float Ku = ((b[5] * 1.0001f + 1e-4f) + 1e-5f * c1) * 1.000001f;
+          out[0] = b[0]; out[1] = b[1]; out[2] = b[2];
+          out[3] = b[4] - 2e-4f;
+          out[4] = Kl < __builtin_inff() ? Kl : __builtin_nanf("");
+          out[5] = b[6] + 2e-4f;
+          out[6] = Ku < __builtin_inff() ? Ku : __builtin_inff();
+          out[7] = 0.0f;
+          q = end + 1;
+        }
       }
       if (w.x == RM_OP_CULL_MIN) {
         float b7[7];

@@ -1,6 +1,7 @@
 """Fuzz of the exactness of CULL_LSE (exact culling inside smooth unions): random blobs (tests/helpers.random_blob_spec:
 8-40 affine-placed random subtrees under one SDFSmoothUnion, un-normalised quaternions, nested unions / smooth unions
-inside the children) compiled with the culling (RM_CULL_LSE=1, from 2 children on) and without (RM_CULL_LSE=0); values at
+inside the children) compiled with the culling (RM_CULL_LSE=1, from 2 children on; RM_CULL_UNION_TABLE=1: a blob under a
+min-union is also skipped as a whole from its children's own bounds) and without (both 0); values at
 16 k points and point gradients must be bit-identical, parameter gradients equal to summation order (the longer
 program changes the interpreter's LDS footprint and with it the block size, see tests/fuzz_cull.py), and frames rendered
 through the interpreter bit-identical.
@@ -32,6 +33,7 @@ for seed in range(n_seeds):
     res = {}
     for cull in ("0", "1"):
         os.environ["RM_CULL_LSE"] = cull
+        os.environ["RM_CULL_UNION_TABLE"] = cull         # ... and the whole-union test from the children's own bounds
         module = H.spec_to_module(spec).to(dev)
         cs = compiled_for(module)
         n_sites = int((cs.program.reshape(-1, 4)[:, 0] == _abi.OP_CULL_LSE).sum())

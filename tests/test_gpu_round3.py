@@ -90,6 +90,7 @@ def test_smooth_union_culling_changes_no_bit(case, monkeypatch):
         specialize._loaded.clear()
         for cull in ("0", "1"):
             monkeypatch.setenv("RM_CULL_LSE", cull)
+            monkeypatch.setenv("RM_CULL_UNION_TABLE", cull)      # and the whole-union test from the children's own bounds
             module = make().to(DEV)
             cs = compiled_for(module)
             n_sites = int((cs.program.reshape(-1, 4)[:, 0] == _abi.OP_CULL_LSE).sum())
