@@ -8,3 +8,4 @@ python3 bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_def
 python3 bench.py --config 5 --steps 3 --warmup 1 --repeats 3 > gpurun_out/r03_config5_1gpu.json 2> gpurun_out/r03_config5_1gpu.err; echo "bench c5 rc=$?"
 python3 bench.py --gpus 2 --share-gpu --backend gloo --steps 5 --warmup 2 --skip-backward --no-pipelined > gpurun_out/r03_rehearsal_selflaunch_2rank.json 2> gpurun_out/r03_rehearsal_selflaunch_2rank.err; echo "selflaunch rc=$?"
 timeout -k 10 500 python3 tests/fuzz_cull_lse.py 100 > gpurun_out/r03_fuzz_cull_lse.txt 2>&1; echo "fuzz rc=$?"
+RM_CULL_LSE_MIN=2 timeout -k 10 500 python3 tests/fuzz_cull.py 200 > gpurun_out/r03_fuzz_cull.txt 2>&1; echo "fuzz cull rc=$?"

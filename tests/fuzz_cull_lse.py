@@ -20,7 +20,7 @@ from ray_marching_amd.compiler import compiled_for
 dev = torch.device("cuda:0")
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 same = lambda x, y: torch.equal(torch.nan_to_num(x, nan=1234.5), torch.nan_to_num(y, nan=1234.5)) and torch.equal(x.isnan(), y.isnan())
-bad, sites = [], 0
+bad, sites, union_sites = [], 0, 0
 for seed in range(n_seeds):
     gen = torch.Generator().manual_seed(700000 + seed)
     spec, spread = H.random_blob_spec(gen)
@@ -36,7 +36,10 @@ for seed in range(n_seeds):
         os.environ["RM_CULL_UNION_TABLE"] = cull         # ... and the whole-union test from the children's own bounds
         module = H.spec_to_module(spec).to(dev)
         cs = compiled_for(module)
-        n_sites = int((cs.program.reshape(-1, 4)[:, 0] == _abi.OP_CULL_LSE).sum())
+        rows_ = cs.program.reshape(-1, 4)
+        n_sites = int((rows_[:, 0] == _abi.OP_CULL_LSE).sum())
+        if cull == "1":
+            union_sites += int(((rows_[:, 0] == _abi.OP_CULL_MIN) & (rows_[:, 1] == 1)).sum())
         p = pts.clone().requires_grad_(True)
         try:
             d = module(p)
@@ -65,5 +68,5 @@ for seed in range(n_seeds):
         bad.append(seed)
         print(f"seed {seed}: MISMATCH ({b[3]} sites) values {same(a[0], b[0])} point grads {same(a[1], b[1])} "
               f"frames {[same(x, y) for x, y in zip(a[4], b[4])]}", flush=True)
-print(f"{n_seeds} random blobs, {sites} CULL_LSE sites: {len(bad)} mismatches {bad}")
+print(f"{n_seeds} random blobs, {sites} CULL_LSE sites, {union_sites} smooth unions culled as a whole from their children's bounds: {len(bad)} mismatches {bad}")
 sys.exit(1 if bad else 0)
