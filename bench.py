@@ -246,9 +246,21 @@ def reference_shape_probe(dev):
                 loop.display_frame(q, t, mode, 1, steps)
                 torch.cuda.synchronize()
             fused_waited = (time.perf_counter() - t0) / n * 1e3
+            # ... and replayed from a HIP graph (RenderLoop.capture(display=True)): the host side of a 0.14 ms frame matters
+            shot = loop.capture(mode, 1, steps, display=True)
+            for _ in range(10):
+                shot(q, t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                shot(q, t)
+                torch.cuda.synchronize()
+            graph_waited = (time.perf_counter() - t0) / n * 1e3
+            del shot
             out["modes"][name] = {"ms_per_frame": free, "fps": 1e3 / free, "ms_per_frame_waited": waited,
                                   "fps_waited": 1e3 / waited, "render_only_ms": render,
                                   "display_frame_ms_waited": fused_waited, "display_frame_fps_waited": 1e3 / fused_waited,
+                                  "display_graph_ms_waited": graph_waited, "display_graph_fps_waited": 1e3 / graph_waited,
                                   "Mrays_per_s": h * w / free / 1e3}
     return out
 

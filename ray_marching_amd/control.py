@@ -35,8 +35,12 @@ class CapturedFrame:
     re-allocated parameter only a refresh of the pointer table.  Changing mode, steps, resolution or the scene
     topology needs a new capture.  Inference only (no autograd)."""
 
-    def __init__(self, loop: "RenderLoop", mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None):
+    def __init__(self, loop: "RenderLoop", mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None,
+                 display: bool = False):
+        """``display=True``: the replay writes main.py:78-84's display tensor ([H,W,4] fp32, alpha 1: RenderLoop.display_frame)
+        instead of the [N,H,W,3] image (one camera)."""
         self.loop, self.mode, self.degree, self.steps, self.rows = loop, mode % 8, int(degree), int(marching_steps), rows
+        self.display = bool(display)
         rp, rd = loop._io_buffers(False)
         dev, n = rp.device, rp.shape[0]
         self.cs = compiled_for(loop.scene)
@@ -62,7 +66,8 @@ class CapturedFrame:
 
         def frame(order=None, cost=None):
             return ops.render_frame(None, self.q, self.t, static, rp, rd, loop.normals.tetra(), cmap,
-                                    self.mode, self.degree, self.steps, rows, flags, None, loop.precision, None, order, cost)
+                                    self.mode, self.degree, self.steps, rows, flags, None, loop.precision,
+                                    "rgba" if self.display else None, order, cost)
 
         # regen=True: the regeneration kernels need a dealing order that follows the camera.  Two graphs share the
         # static buffers: the plain frame, and a frame that also records the ray costs and renews the order behind it;
@@ -365,9 +370,9 @@ class RenderLoop(nn.Module):
                                                         _abi.ptr(st["scratch"]), stream), "rm_tile_order_from_cost")
         st["valid"] = True
 
-    def capture(self, mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None) -> CapturedFrame:
-        """HIP-graph replay of one inference frame (see CapturedFrame)."""
-        return CapturedFrame(self, mode, degree, marching_steps, rows)
+    def capture(self, mode: int = 0, degree: int = 1, marching_steps: int = 32, rows=None, display: bool = False) -> CapturedFrame:
+        """HIP-graph replay of one inference frame (see CapturedFrame); ``display=True``: of the [H,W,4] display tensor."""
+        return CapturedFrame(self, mode, degree, marching_steps, rows, display)
 
     def training_step(self, loss_fn, mode: int = 0, degree: int = 1, marching_steps: int = 32, optimizer=None,
                       pose_requires_grad: bool = False):

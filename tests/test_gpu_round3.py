@@ -309,6 +309,13 @@ def test_display_frame_is_the_three_pass_display_contract(dtype):
             assert img.dtype == torch.float64
             want = F.pad(img.mean(dim=0).float(), pad=[0, 1], value=1.0)
             assert torch.equal(torch.nan_to_num(loop.display_frame(q.float(), t.float(), mode, 3, steps), nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+    # the same tensor replayed from a HIP graph, pose changing between replays
+    shot = loop.capture(4, 1, steps, display=True)
+    for z in (1.0, -2.0):
+        tz = torch.tensor([[0.0, 0.0, z]], device=DEV)
+        with torch.no_grad():
+            want = loop.display_frame(q.float(), tz, 4, 1, steps)
+        assert torch.equal(shot(q.float(), tz), want)
     with pytest.raises(ValueError):
         H.make_loop(H.spec_to_module(O.scene_test2()), 16, 16, n=2).display_frame(torch.tensor([[1.0, 0, 0, 0]] * 2, device=DEV),
                                                                                   torch.zeros(2, 3, device=DEV))
