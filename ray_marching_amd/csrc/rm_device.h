@@ -166,6 +166,17 @@ RM_DEV float aten_inner_sum_n(F e) {
 // ATen vector_norm (p=2) on CPU: FMA chain then correctly rounded sqrt.
 RM_DEV float norm3(V3 a) { return rm_sqrt(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
 RM_DEV float norm2(float a, float b) { return rm_sqrt(__builtin_fmaf(b, b, a * a)); }
+// Inside a VJP nothing has to be bit-exact (the gradient contract is 1e-4; a VJP's own forward half only feeds
+// sub-gradient choices and softmax weights): kFast takes the bare 1-ulp v_sqrt_f32 / v_rcp_f32 in place of the
+// 9-instruction exact square root and the ~10-instruction IEEE division.  Values (march, distances, normals, images)
+// never come through kFast = true.
+#ifndef RM_FAST_VJP
+#define RM_FAST_VJP 1
+#endif
+template <bool kFast> RM_DEV float sqrt_t(float x) { return kFast ? __builtin_amdgcn_sqrtf(x) : rm_sqrt(x); }
+template <bool kFast> RM_DEV float norm3_t(V3 a) { return sqrt_t<kFast>(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
+template <bool kFast> RM_DEV float norm2_t(float a, float b) { return sqrt_t<kFast>(__builtin_fmaf(b, b, a * a)); }
+template <bool kFast> RM_DEV float div_t(float a, float b) { return kFast ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 // quaternion.py:55-72: V + w*t + qv x t, t = 2*(qv x V); summed as (y + w*t) + V.
 RM_DEV V3 qrot(V3 v, float w, V3 qv) {
   V3 t = 2.0f * cross(qv, v);
@@ -279,8 +290,9 @@ struct RegParams {
 #define RM_CULL_TRACKED 2   // cull sites per scene whose decision is carried from step to step (2 VGPRs each)
 #endif
 
-template <class Store>
+template <class Store, bool Fast = false>
 struct Fwd {
+  static constexpr bool kFast = Fast;   // forward half of a VJP: 1-ulp square roots (sqrt_t)
   V3 p;        // query point in the current (innermost affine) frame
   float d;     // value register: distance produced by the last node
   float acc;   // running min of the innermost open SDFUnion
@@ -419,7 +431,7 @@ template <class S, class PT>
 RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
   switch (op) {
     case RM_OP_SPHERE:  // |p| - r
-      s.d = norm3(s.p) - P[off];
+      s.d = norm3_t<S::kFast>(s.p) - P[off];
       break;
     case RM_OP_BOX: {  // |relu(q)| + min(max(q),0), q = |p| - h
       float qx = fabsf(s.p.x) - P[off], qy = fabsf(s.p.y) - P[off + 1], qz = fabsf(s.p.z) - P[off + 2];
@@ -428,7 +440,7 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       // for the whole wave (rays inside a room shell: always) the norm -- 3 max, mul, 2 fma and the
       // 9-instruction exact sqrt -- is skipped.  NaN fails (m <= 0) and takes the full path.
       float nr = 0.0f;
-      if (!__all(m <= 0.0f)) nr = norm3(mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz)));
+      if (!__all(m <= 0.0f)) nr = norm3_t<S::kFast>(mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz)));
       s.d = nr + ((m < 0.0f) ? m : 0.0f);
     } break;
     case RM_OP_PLANE:
@@ -439,15 +451,15 @@ RM_DEV void fwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       V3 ap = s.p - P.v3(off);
       float h = t_clamp(dot_seq(ap, abs_), 0.0f, 1.0f);
       V3 w = mk3(h * ab.x - ap.x, h * ab.y - ap.y, h * ab.z - ap.z);
-      s.d = norm3(w) - P[off + 6];
+      s.d = norm3_t<S::kFast>(w) - P[off + 6];
     } break;
     case RM_OP_DISK: {  // axis x, radius in yz
-      float rd = norm2(s.p.y, s.p.z) - P[off];
-      s.d = norm2(s.p.x, t_relu_keep(rd));
+      float rd = norm2_t<S::kFast>(s.p.y, s.p.z) - P[off];
+      s.d = norm2_t<S::kFast>(s.p.x, t_relu_keep(rd));
     } break;
     case RM_OP_TORUS: {  // ring in xz
-      float ring = norm2(s.p.x, s.p.z) - P[off];
-      s.d = norm2(ring, s.p.y) - P[off + 1];
+      float ring = norm2_t<S::kFast>(s.p.x, s.p.z) - P[off];
+      s.d = norm2_t<S::kFast>(ring, s.p.y) - P[off + 1];
     } break;
     case RM_OP_AFFINE_PUSH: {  // child(rot(p - t, conj(q)))
       s.st->st(s.sp, s.p.x); s.st->st(s.sp + 1, s.p.y); s.st->st(s.sp + 2, s.p.z);
@@ -552,9 +564,10 @@ RM_DEV void smooth_end_static(S& s, const PT& P, int off) {
 // Gradient accumulators live in the store at index acc0 + parameter offset
 // (raw parameters first, derived constants after them).
 // --------------------------------------------------------------------------
-template <class Store, bool Acc = true>
+template <class Store, bool Acc = true, bool Fast = (RM_FAST_VJP != 0)>
 struct Bwd {
   static constexpr bool kAcc = Acc;   // false: point gradient only (no parameter accumulators are touched)
+  static constexpr bool kFast = Fast; // 1-ulp square roots and reciprocals (sqrt_t, div_t)
   V3 p;
   V3 gp;
   float g;
@@ -576,7 +589,7 @@ RM_DEV void padd(S& s, int i, float v) {
 template <class S>
 RM_DEV V3 safe_unit_scaled(V3 w, float n, float g) {
   // torch norm backward: self * (grad / norm), 0 where norm == 0.
-  float s = (n == 0.0f) ? 0.0f : g / n;
+  float s = (n == 0.0f) ? 0.0f : div_t<S::kFast>(g, n);
   return mk3(w.x * s, w.y * s, w.z * s);
 }
 
@@ -585,7 +598,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
   const int A = s.acc0;
   switch (op) {
     case RM_OP_SPHERE: {
-      float n = norm3(s.p);
+      float n = norm3_t<S::kFast>(s.p);
       s.gp = s.gp + safe_unit_scaled<S>(s.p, n, s.g);
       padd(s, A + off, -s.g);
     } break;
@@ -593,7 +606,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       float qx = fabsf(s.p.x) - P[off], qy = fabsf(s.p.y) - P[off + 1], qz = fabsf(s.p.z) - P[off + 2];
       float m = t_max(t_max(qx, qy), qz);
       V3 r = mk3(t_relu_keep(qx), t_relu_keep(qy), t_relu_keep(qz));
-      float nr = norm3(r);
+      float nr = norm3_t<S::kFast>(r);
       V3 gr = safe_unit_scaled<S>(r, nr, s.g);
       // where(q > 0): gradient only where q > 0 ; max(dim): first index attaining the max
       float gm = (m < 0.0f) ? s.g : 0.0f;
@@ -613,7 +626,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       float h0 = dot_seq(ap, abs_);
       float h = t_clamp(h0, 0.0f, 1.0f);
       V3 w = mk3(h * ab.x - ap.x, h * ab.y - ap.y, h * ab.z - ap.z);
-      float nw = norm3(w);
+      float nw = norm3_t<S::kFast>(w);
       V3 gw = safe_unit_scaled<S>(w, nw, s.g);
       float gh = (gw.x * ab.x + gw.y * ab.y) + gw.z * ab.z;
       float gh0 = (h0 >= 0.0f && h0 <= 1.0f) ? gh : 0.0f;  // clamp passes grad on the closed interval
@@ -625,24 +638,24 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       padd(s, A + a0 + 3, gh0 * ap.x); padd(s, A + a0 + 4, gh0 * ap.y); padd(s, A + a0 + 5, gh0 * ap.z);  // d(AB/|AB|^2)
     } break;
     case RM_OP_DISK: {
-      float a = norm2(s.p.y, s.p.z);
+      float a = norm2_t<S::kFast>(s.p.y, s.p.z);
       float rd = a - P[off];
       float c = t_relu_keep(rd);
-      float d = norm2(s.p.x, c);
-      float sc = (d == 0.0f) ? 0.0f : s.g / d;
+      float d = norm2_t<S::kFast>(s.p.x, c);
+      float sc = (d == 0.0f) ? 0.0f : div_t<S::kFast>(s.g, d);
       float gc = c * sc;
       float grd = (rd > 0.0f) ? gc : 0.0f;
-      float sa = (a == 0.0f) ? 0.0f : grd / a;
+      float sa = (a == 0.0f) ? 0.0f : div_t<S::kFast>(grd, a);
       s.gp = s.gp + mk3(s.p.x * sc, s.p.y * sa, s.p.z * sa);
       padd(s, A + off, -grd);
     } break;
     case RM_OP_TORUS: {
-      float a = norm2(s.p.x, s.p.z);
+      float a = norm2_t<S::kFast>(s.p.x, s.p.z);
       float ring = a - P[off];
-      float d0 = norm2(ring, s.p.y);
-      float sc = (d0 == 0.0f) ? 0.0f : s.g / d0;
+      float d0 = norm2_t<S::kFast>(ring, s.p.y);
+      float sc = (d0 == 0.0f) ? 0.0f : div_t<S::kFast>(s.g, d0);
       float gring = ring * sc;
-      float sa = (a == 0.0f) ? 0.0f : gring / a;
+      float sa = (a == 0.0f) ? 0.0f : div_t<S::kFast>(gring, a);
       s.gp = s.gp + mk3(s.p.x * sa, s.p.y * sc, s.p.z * sa);
       padd(s, A + off, -gring);
       padd(s, A + off + 1, -s.g);
@@ -700,7 +713,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       s.gframe = s.g;
       s.fval = L;
       // out = L / (-k): d out / dk through the division
-      padd(s, A + off, s.g * L / (k * k));
+      padd(s, A + off, div_t<S::kFast>(s.g * L, k * k));
     } break;
     case RM_OP_FOLD_LSE: {
       float k = P[off];
@@ -710,7 +723,7 @@ RM_DEV void bwd_op(S& s, const PT& P, int op, int off, int a0, int a1) {
       // on a quantity whose contract is 1e-4 -- keeps 4 to 32 exponentials per VJP off the critical path.
       float w = __builtin_amdgcn_exp2f((di * (-k) - s.fval) * 1.44269504088896340736f);
       s.g = s.gframe * w;
-      padd(s, A + off, (s.gframe / k) * w * di);
+      padd(s, A + off, div_t<S::kFast>(s.gframe, k) * w * di);
     } break;
     case RM_OP_SMOOTH_BEGIN:
       s.sp -= 2; s.gframe = s.st->ld(s.sp); s.fval = s.st->ld(s.sp + 1);
@@ -912,7 +925,7 @@ struct Scene {
   // VJP at point p with upstream g: returns dL/dp, adds parameter grads into the accumulators.
   // `value` (optional) receives f(p) from the recording forward pass.
   RM_DEV V3 vjp(V3 p, float g, float* value = nullptr) const {
-    Fwd<Store> f;
+    Fwd<Store, (RM_FAST_VJP != 0)> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
     f.culled = 0ull; f.lds = lds;
 #pragma unroll
@@ -927,7 +940,7 @@ struct Scene {
   }
   // dL/dp only (upstream g), no parameter gradients: the accumulator arithmetic is compiled out
   RM_DEV V3 vjp_point(V3 p, float g, float* value = nullptr) const {
-    Fwd<Store> f;
+    Fwd<Store, (RM_FAST_VJP != 0)> f;
     f.p = p; f.d = 0.0f; f.acc = __builtin_inff(); f.sp = 0; f.tape0 = tape0; f.st = st; f.record = true;
     f.culled = 0ull; f.lds = lds;
 #pragma unroll

@@ -223,7 +223,7 @@ def test_training_step_helper_matches_the_eager_loop():
             want = loss_fn(twin_loop(q, t, 0, 1, 32))
             want.backward()
             twin_opt.step()
-            assert abs(got_loss - float(want)) <= 1e-6 * max(1.0, abs(float(want))), (got_loss, float(want))
+            assert abs(got_loss - float(want.detach())) <= 1e-6 * max(1.0, abs(float(want.detach()))), (got_loss, float(want.detach()))
             for a, b in zip(scene.parameters(), twin.parameters()):
                 assert float((a - b).detach().abs().max()) <= 1e-6 * max(1.0, float(b.detach().abs().max()))
 
