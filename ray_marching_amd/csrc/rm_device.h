@@ -947,9 +947,23 @@ struct Scene {
     for (int k = 0; k < Prog::kTracked; ++k) { f.cull_lo[k] = __builtin_nanf(""); f.cull_hi[k] = __builtin_nanf(""); }
     prog.forward(f, P);
     if (value) *value = f.d;
+    last_culled = f.culled;
     Bwd<Store, false> b;
     b.p = p; b.gp = mk3(0.0f, 0.0f, 0.0f); b.g = g; b.gframe = 0.0f; b.fval = 0.0f;
     b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st; b.culled = f.culled;
+    prog.backward(b, P);
+    return b.gp;
+  }
+  // The full VJP (parameter gradients included) at the point of the LAST vjp_point / vjp of this context, without its
+  // forward half: the reverse pass only reads the tape slots (fold inputs, onion inputs, the logsumexp value) and the
+  // skip bits, and a reverse pass leaves them as they were (its own saves go to the stack region).  No scene
+  // evaluation may lie in between.  Used by the converged-tail loop of march_reverse: one point-gradient pass at the
+  // anchor, the recursion, then the parameter pass with the summed upstream.
+  mutable unsigned long long last_culled = 0ull;
+  RM_DEV V3 vjp_replay(V3 p, float g) const {
+    Bwd<Store> b;
+    b.p = p; b.gp = mk3(0.0f, 0.0f, 0.0f); b.g = g; b.gframe = 0.0f; b.fval = 0.0f;
+    b.sp = 0; b.tape0 = tape0; b.acc0 = acc0; b.st = st; b.culled = last_culled;
     prog.backward(b, P);
     return b.gp;
   }

@@ -472,7 +472,9 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
       if (more) fill(i - 1);                                    // p_i = win[7] is step i; the window moves on
     }
     cur = p_i;
-    if (__any(G != 0.0f)) scene.vjp(anchor, G);       // parameter gradients of the whole run at once
+    // parameter gradients of the whole run at once: the reverse pass alone, on the tape the point-gradient pass left
+    // (no scene evaluation since: the loop above only loaded iterates)
+    if (__any(G != 0.0f)) scene.vjp_replay(anchor, G);
     if (walked) *walked += 2;
     if (done) { finish_frozen(i); return lam; }
   }
