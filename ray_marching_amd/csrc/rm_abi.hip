@@ -88,9 +88,7 @@ using GF = rm::GenericCfg;
 int check_static(const RmScene*) { return RM_OK; }
 // LDS bytes of the generic path for a block of `block` threads.
 size_t lds_bytes(const RmScene& sc, int block, bool backward) {
-  size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3);
-  size_t per_thread = (size_t)sc.stack_floats + sc.n_slots + (backward ? sc.n_params + sc.n_grad_derived : 0);
-  return 4 * (pb + 4 * (size_t)sc.n_instr + per_thread * (block + 1));
+  return 4 * rm::GenericCfg::lds_floats(sc, block, backward);
 }
 #endif
 

@@ -208,10 +208,17 @@ struct LdsStore {
   float* base;   // per thread
   int stride;    // wave-uniform; readfirstlane keeps i * stride on the scalar unit (as a VGPR value it
                  // costs a quarter-rate v_mul_lo_u32 per access: measured 368 VALU per interpreted eval)
+  // Gradient accumulators (backward kernels): ONE ROW PER WAVE, not a column per thread.  Every accumulation is a wave
+  // sum (6 DPP adds in a fixed order) followed by one read-modify-write from lane 63.  Columns cost 65 x 4 B per
+  // accumulator and 64-thread block: closed scene 1 (46 accumulators) fitted two waves per CU-quarter, the 32-primitive
+  // scene (347) one wave per CU, and 48 primitives did not fit at all; rows cost 4 B per accumulator and wave
+  // (profiles/r03_wide_ab.txt: many32 fwd+bwd 29.4 -> 16.7 ms at 256^2, closed scene 1 1.22 -> 1.15 ms at 512^2).
+  float* acc_row;   // this wave's row; nullptr in forward kernels
+  int acc0;         // store index of accumulator 0
   RM_DEV int at(int i) const { return uniform_i(i) * uniform_i(stride); }
   RM_DEV float ld(int i) const { return base[at(i)]; }
   RM_DEV void st(int i, float v) { base[at(i)] = v; }
-  RM_DEV void add(int i, float v) { base[at(i)] += v; }
+  RM_DEV void add(int i, float v);
 };
 
 // Registers: with a StaticProgram every index is a compile-time constant after
@@ -359,6 +366,24 @@ RM_DEV float wave_reduce(float v) {
   v = comb(v, RM_DPP_F(v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
   v = comb(v, RM_DPP_F(v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Sum over the 64 lanes in a fixed order (the same DPP ladder; lanes without a source add 0); the result is in lane 63.
+// Needs every lane active, as above.
+#define RM_DPP_Z(x, ctrl, row_mask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (row_mask), 0xf, true))
+RM_DEV float wave_sum_lane63(float v) {
+  v += RM_DPP_Z(v, 0x111, 0xf);
+  v += RM_DPP_Z(v, 0x112, 0xf);
+  v += RM_DPP_Z(v, 0x114, 0xf);
+  v += RM_DPP_Z(v, 0x118, 0xf);
+  v += RM_DPP_Z(v, 0x142, 0xa);
+  v += RM_DPP_Z(v, 0x143, 0xc);
+  return v;
+}
+RM_DEV void LdsStore::add(int i, float v) {
+  const float sum = wave_sum_lane63(v);
+  if ((threadIdx.x & 63) == 63) acc_row[uniform_i(i) - acc0] += sum;
 }
 
 // Exact culling inside a smooth union (RM_OP_SMOOTH_BEGIN with a bound table, RM_OP_CULL_LSE).

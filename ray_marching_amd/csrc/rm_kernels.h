@@ -29,6 +29,13 @@ struct GenericCfg {
   using SceneT = Scene<Prog, Store, LdsParams>;
   static constexpr bool kStatic = false;
   static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_grad_derived; }
+  // LDS floats of a block of `block` threads: parameter block, program, per thread one column (+1 of padding) of
+  // evaluation stack and tape, and -- backward -- one row of gradient accumulators per wave (LdsStore::acc_row).
+  static __host__ __device__ size_t lds_floats(const RmScene& sc, int block, bool backward) {
+    return (size_t)((sc.n_params + sc.n_derived + 3) & ~3) + 4 * (size_t)sc.n_instr +
+           ((size_t)sc.stack_floats + sc.n_slots) * (block + 1) +
+           (backward ? (size_t)(sc.n_params + sc.n_grad_derived) * (block >> 6) : 0);
+  }
 
   // returns the scene context; `store` must outlive it
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool scalar_fetch = false) {
@@ -39,6 +46,9 @@ struct GenericCfg {
     stage_scene(sc, s_params, s_prog);
     store.base = s_store + threadIdx.x;
     store.stride = blockDim.x + 1;
+    store.acc0 = sc.stack_floats + sc.n_slots;
+    store.acc_row = scalar_fetch      // (= a backward kernel)
+        ? s_store + (size_t)(sc.stack_floats + sc.n_slots) * (blockDim.x + 1) + (threadIdx.x >> 6) * n_acc(sc) : nullptr;
     SceneT s;
     // Instruction fetch: LDS broadcast read + readfirstlane in the forward kernels; in the backward
     // kernels, where LDS is busy with the per-thread gradient accumulators, straight from the program
@@ -121,7 +131,8 @@ RM_DEV void zero_accumulators(const typename Cfg::SceneT& sc, int n_acc) {
 #pragma unroll
     for (int i = 0; i < Cfg::kAcc; ++i) sc.st->st(sc.acc0 + i, 0.0f);   // constant indices: stays in VGPRs
   } else {
-    for (int i = 0; i < n_acc; ++i) sc.st->st(sc.acc0 + i, 0.0f);
+    // this wave's row (LDS operations of one wave complete in order: no barrier before the first accumulation)
+    for (int i = threadIdx.x & 63; i < n_acc; i += 64) sc.st->acc_row[i] = 0.0f;
   }
 }
 
@@ -130,13 +141,10 @@ template <class Cfg>
 RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float* partials, float* smem_scratch) {
   if constexpr (!Cfg::kStatic) {
     __syncthreads();
-    // LDS columns: element i of thread t at base[i*stride + t]
-    const float* col0 = sc.st->base - threadIdx.x;
-    int stride = sc.st->stride;
+    const float* rows = sc.st->acc_row - (threadIdx.x >> 6) * n_acc;      // one row per wave, added in wave order
     for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
-      const float* row = col0 + (int64_t)(sc.acc0 + i) * stride;
       float sum = 0.0f;
-      for (int t = 0; t < (int)blockDim.x; ++t) sum += row[t];
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += rows[w * n_acc + i];
       partials[(int64_t)blockIdx.x * n_acc + i] = sum;
     }
   } else {
