@@ -385,6 +385,17 @@ RM_DEV void LdsStore::add(int i, float v) {
   const float sum = wave_sum_lane63(v);
   if ((threadIdx.x & 63) == 63) acc_row[uniform_i(i) - acc0] += sum;
 }
+// The same accumulator rows on top of a register / hybrid store (specialised backward of scenes with too many
+// accumulators for registers: StaticCfg::kRowAcc); `i - acc0` is a compile-time constant after inlining.
+template <class Base>
+struct RowAccStore : Base {
+  float* acc_row;
+  int acc0;
+  RM_DEV void add(int i, float v) {
+    const float sum = wave_sum_lane63(v);
+    if ((threadIdx.x & 63) == 63) acc_row[i - acc0] += sum;
+  }
+};
 
 // Exact culling inside a smooth union (RM_OP_SMOOTH_BEGIN with a bound table, RM_OP_CULL_LSE).
 // torch.logsumexp(-k d) = log(sum_i exp(x_i - m)) + m with x_i = -k d_i, m = max x.  exp(x) is EXACTLY +0.0f below

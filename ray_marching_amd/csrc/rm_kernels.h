@@ -28,13 +28,18 @@ struct GenericCfg {
   using Prog = RuntimeProgram;
   using SceneT = Scene<Prog, Store, LdsParams>;
   static constexpr bool kStatic = false;
+  static constexpr bool kRowAcc = true;
   static RM_DEV int n_acc(const RmScene& sc) { return sc.n_params + sc.n_grad_derived; }
   // LDS floats of a block of `block` threads: parameter block, program, per thread one column (+1 of padding) of
-  // evaluation stack and tape, and -- backward -- one row of gradient accumulators per wave (LdsStore::acc_row).
+  // evaluation stack and tape, and -- backward -- one row of gradient accumulators per wave (LdsStore::acc_row).  The
+  // backward kernels fetch instructions through the scalar cache, so the staged program only serves derive_constants
+  // and shares its space with the columns and rows (setup() returns behind derive_constants' last barrier).
   static __host__ __device__ size_t lds_floats(const RmScene& sc, int block, bool backward) {
-    return (size_t)((sc.n_params + sc.n_derived + 3) & ~3) + 4 * (size_t)sc.n_instr +
-           ((size_t)sc.stack_floats + sc.n_slots) * (block + 1) +
-           (backward ? (size_t)(sc.n_params + sc.n_grad_derived) * (block >> 6) : 0);
+    const size_t pb = (size_t)((sc.n_params + sc.n_derived + 3) & ~3), prog = 4 * (size_t)sc.n_instr;
+    const size_t columns = ((size_t)sc.stack_floats + sc.n_slots) * (block + 1);
+    if (!backward) return pb + prog + columns;
+    const size_t work = columns + (size_t)(sc.n_params + sc.n_grad_derived) * (block >> 6);
+    return pb + (prog > work ? prog : work);
   }
 
   // returns the scene context; `store` must outlive it
@@ -42,7 +47,7 @@ struct GenericCfg {
     int pb = (sc.n_params + sc.n_derived + 3) & ~3;
     float* s_params = smem;
     int4* s_prog = reinterpret_cast<int4*>(smem + pb);
-    float* s_store = smem + pb + 4 * sc.n_instr;
+    float* s_store = smem + pb + (scalar_fetch ? 0 : 4 * sc.n_instr);
     stage_scene(sc, s_params, s_prog);
     store.base = s_store + threadIdx.x;
     store.stride = blockDim.x + 1;
@@ -69,11 +74,19 @@ struct GenericCfg {
 #ifndef RM_LDS_TAPE_MIN_SLOTS
 #define RM_LDS_TAPE_MIN_SLOTS 17   // scenes with at least this many tape slots keep the tape in LDS columns (HybridStore)
 #endif
+#ifndef RM_STATIC_REG_ACC_MAX
+#define RM_STATIC_REG_ACC_MAX 96
+#endif
 template <class Code, int kRegParamLimit = 64, bool kVgprParams = false>
 struct StaticCfg {
-  static constexpr int kStoreN = Code::stack_floats + Code::n_slots + Code::n_params + Code::n_grad_derived;
+  static constexpr int kAcc = Code::n_params + Code::n_grad_derived;     // gradient accumulators
+  // up to RM_STATIC_REG_ACC_MAX of them ride in registers, one set per ray (closed scene 1: 46); more would spill, so
+  // larger scenes keep one row per wave in LDS like the interpreter (RowAccStore)
+  static constexpr bool kRowAcc = kAcc > RM_STATIC_REG_ACC_MAX;
+  static constexpr int kStoreN = Code::stack_floats + Code::n_slots + (kRowAcc ? 0 : kAcc);
   static constexpr bool kLdsTape = Code::n_slots >= RM_LDS_TAPE_MIN_SLOTS;
-  using Store = std::conditional_t<kLdsTape, HybridStore<Code::stack_floats, Code::n_slots, kStoreN>, RegStore<kStoreN>>;
+  using BaseStore = std::conditional_t<kLdsTape, HybridStore<Code::stack_floats, Code::n_slots, kStoreN>, RegStore<kStoreN>>;
+  using Store = std::conditional_t<kRowAcc, RowAccStore<BaseStore>, BaseStore>;
   using Prog = StaticProgram<Code>;
   // small parameter blocks ride in registers; big ones (config 5: 381 floats) stay in LDS
   static constexpr int kParamFloats = Code::n_params + Code::n_derived;
@@ -81,7 +94,6 @@ struct StaticCfg {
   using PT = std::conditional_t<kRegParams, RegParams<kParamFloats, kVgprParams>, LdsParams>;
   using SceneT = Scene<Prog, Store, PT>;
   static constexpr bool kStatic = true;
-  static constexpr int kAcc = Code::n_params + Code::n_grad_derived;     // gradient accumulators per ray
   static RM_DEV int n_acc(const RmScene&) { return kAcc; }
 
   // floats of the block's tape area (after the parameter block and, in backward kernels, the reduction scratch)
@@ -90,9 +102,11 @@ struct StaticCfg {
   static RM_DEV SceneT setup(const RmScene& sc, float* smem, Store& store, bool backward = false) {
     // the parameter block is still staged through LDS (raw + derived), the program is not
     float* s_params = smem;
-    if constexpr (kLdsTape) {
-      const int pb = (Code::n_params + Code::n_derived + 3) & ~3;
-      store.base = smem + pb + 4 + (backward ? (int)(blockDim.x >> 6) * kAcc : 0) + threadIdx.x;
+    constexpr int pb = (Code::n_params + Code::n_derived + 3) & ~3;
+    if constexpr (kLdsTape) store.base = smem + pb + 4 + (backward ? (int)(blockDim.x >> 6) * kAcc : 0) + threadIdx.x;
+    if constexpr (kRowAcc) {      // the rows are the block-reduction scratch of the register form (flush_accumulators)
+      store.acc0 = Code::stack_floats + Code::n_slots;
+      store.acc_row = backward ? smem + pb + (int)(threadIdx.x >> 6) * kAcc : nullptr;
     }
     stage_params(sc, s_params, Code::n_params);
     __syncthreads();
@@ -127,19 +141,19 @@ extern __shared__ __attribute__((aligned(16))) float rm_smem[];
 // ---------------------------------------------------------------------------
 template <class Cfg>
 RM_DEV void zero_accumulators(const typename Cfg::SceneT& sc, int n_acc) {
-  if constexpr (Cfg::kStatic) {
-#pragma unroll
-    for (int i = 0; i < Cfg::kAcc; ++i) sc.st->st(sc.acc0 + i, 0.0f);   // constant indices: stays in VGPRs
-  } else {
+  if constexpr (Cfg::kRowAcc) {
     // this wave's row (LDS operations of one wave complete in order: no barrier before the first accumulation)
     for (int i = threadIdx.x & 63; i < n_acc; i += 64) sc.st->acc_row[i] = 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < Cfg::kAcc; ++i) sc.st->st(sc.acc0 + i, 0.0f);   // constant indices: stays in VGPRs
   }
 }
 
 // partials[blockIdx.x][n_acc]: deterministic (fixed lane order) sum over the block.
 template <class Cfg>
 RM_DEV void flush_accumulators(const typename Cfg::SceneT& sc, int n_acc, float* partials, float* smem_scratch) {
-  if constexpr (!Cfg::kStatic) {
+  if constexpr (Cfg::kRowAcc) {
     __syncthreads();
     const float* rows = sc.st->acc_row - (threadIdx.x >> 6) * n_acc;      // one row per wave, added in wave order
     for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {

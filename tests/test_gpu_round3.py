@@ -372,3 +372,47 @@ def test_backward_of_wide_scenes(n_prims, monkeypatch):
     mine = torch.cat([x.grad.flatten().cpu() for x in mod.parameters()])
     theirs = torch.cat([x.grad.flatten() for _, x in named])
     assert float((mine - theirs).abs().max()) <= 1e-4 * float(theirs.abs().max()), "frame parameter gradients"
+
+
+def test_specialised_backward_with_row_accumulators(monkeypatch):
+    """RM_STATIC_BACKWARD_ACC (opt-in): the per-scene library of a scene with more gradient accumulators than fit in
+    registers (> 96) is built WITH its backward kernels, which then keep one accumulator row per wave in LDS
+    (StaticCfg::kRowAcc).  Same gradients as the interpreter's backward, to summation order, through `module(points)`
+    and through a frame; hipcc builds the library here (~1 min for 12 primitives)."""
+    from ray_marching_amd import specialize
+    from ray_marching_amd.compiler import compiled_for
+    from ray_marching_amd.scene.scene_registry import make_many_primitive_scene
+    if not os.path.exists(specialize._hipcc()):
+        pytest.skip("no hipcc on this box")
+    gen = torch.Generator().manual_seed(99)
+    pts = ((torch.rand(4096, 3, generator=gen) * 2 - 1) * 4.0).to(DEV)
+    w = torch.randn(4096, 1, generator=gen).to(DEV)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -4.0]], device=DEV)
+    target = torch.rand(1, 48, 64, 1, generator=gen).to(DEV)
+    got = {}
+    for path in ("off", "jit"):
+        monkeypatch.setenv("RM_SPECIALIZE", path)
+        monkeypatch.setenv("RM_STATIC_BACKWARD_ACC", "400")
+        specialize._loaded.clear()
+        mod = make_many_primitive_scene(12).to(DEV)
+        cs = compiled_for(mod)
+        assert cs.n_params + cs.n_grad_derived > specialize.MAX_STATIC_BACKWARD_ACC and specialize.static_backward(cs)
+        assert cs.specialised == (path == "jit")
+        from ray_marching_amd import _abi
+        assert (cs.lib(True) is not _abi.lib) == (path == "jit")        # the backward comes from the per-scene library
+        p = pts.clone().requires_grad_(True)
+        d = mod(p)
+        (d * w).sum().backward()
+        g1 = torch.cat([x.grad.flatten() for x in mod.parameters()])
+        for x in mod.parameters():
+            x.grad = None
+        loop = H.make_loop(mod, 48, 64)
+        img = loop(q, t, 0, 1, 64)
+        (img[..., :1] - target).pow(2).mean().backward()
+        g2 = torch.cat([x.grad.flatten() for x in mod.parameters()])
+        got[path] = (d.detach(), p.grad, g1, img.detach(), g2)
+    a, b = got["off"], got["jit"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-6
+    for i in (2, 4):
+        assert float((a[i] - b[i]).abs().max()) <= 2e-5 * float(a[i].abs().max()), i
