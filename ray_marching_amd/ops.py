@@ -8,6 +8,7 @@ on a HIP device: there is deliberately no CPU path.
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 
@@ -31,11 +32,18 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_warned_f64: list = []
+
+
 def _io(t: torch.Tensor):
     """Contiguous tensor the kernels can read as is (fp32 or fp16; anything else is converted to fp32)
     and its RM_DTYPE_* code."""
     t = t.detach()
     if t.dtype not in (torch.float32, torch.float16):
+        if t.dtype == torch.float64 and not _warned_f64:
+            _warned_f64.append(True)
+            warnings.warn("ray_marching_amd: float64 input -- the HIP kernels compute in float32 (the reference would "
+                          "evaluate a .double() scene in float64); the result is cast back to float64", stacklevel=3)
         t = t.float()
     return t.contiguous(), _abi.dtype_code(t.dtype)
 
