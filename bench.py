@@ -773,7 +773,14 @@ def main():
 
     log(f"rank {rank}/{world}: warm-up {args.warmup}, timing {args.repeats} x {args.steps} steps"
         + (f" (config 5: rows {band})" if config5 else ""))
+    settle = 0
     with torch.no_grad():
+        if config5 and not stub and loop.regen == "auto":
+            # RenderLoop's regen="auto" compares its two frame kernels on the first frames of 16-frame cycles;
+            # a run of a handful of 65-ms frames would be over before the first comparison
+            settle = 36
+            for _ in range(settle):
+                one_step(False)
         for _ in range(args.warmup):
             one_step(False)
         blocks = [timed_block() for _ in range(max(1, args.repeats))]
@@ -802,6 +809,7 @@ def main():
         roof = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kernel_in_use(loop), "kernel_ms": per_launch_ms,
+                **({"kernel_choice": f"regen='auto' after {settle} untimed settling frames"} if settle else {}),
                 "algorithmic_bytes_per_launch": launch_rays * BYTES_PER_RAY,
                 "binding": "fp32-valu issue (SURVEY D8: ~300 flop/B, the fused frame cannot be HBM bound)"}
         if not config5:
