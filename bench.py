@@ -781,6 +781,7 @@ def main():
             settle = 36
             for _ in range(settle):
                 one_step(False)
+                sync()          # every frame waited for, like main.py's window.draw: the choice is made between frames
         for _ in range(args.warmup):
             one_step(False)
         blocks = [timed_block() for _ in range(max(1, args.repeats))]
@@ -809,7 +810,7 @@ def main():
         roof = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kernel_in_use(loop), "kernel_ms": per_launch_ms,
-                **({"kernel_choice": f"regen='auto' after {settle} untimed settling frames"} if settle else {}),
+                **({"kernel_choice": f"regen='auto' after {settle} untimed settling frames, each waited for"} if settle else {}),
                 "algorithmic_bytes_per_launch": launch_rays * BYTES_PER_RAY,
                 "binding": "fp32-valu issue (SURVEY D8: ~300 flop/B, the fused frame cannot be HBM bound)"}
         if not config5:
