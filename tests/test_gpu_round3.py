@@ -416,3 +416,39 @@ def test_specialised_backward_with_row_accumulators(monkeypatch):
     assert float((a[1] - b[1]).abs().max()) <= 1e-6
     for i in (2, 4):
         assert float((a[i] - b[i]).abs().max()) <= 2e-5 * float(a[i].abs().max()), i
+
+
+@pytest.mark.parametrize("mode", [0, 4, 6])
+def test_two_camera_batch_trains(mode, monkeypatch):
+    """num_cameras = 2 (control.py:201; main.py averages the batch for display) with everything requiring grad: scene
+    parameters, both orientations and both translations -- `k_render_bwd`, the deferred-ray kernels and `k_camera_bwd`
+    over a camera batch, against CPU autograd on the oracle.  Both deferred-ray settings (the list and the in-place walk)."""
+    from ray_marching_amd import ops
+    h, w, steps = 40, 48, 48
+    spec = O.map_spec(O.scene_test1_closed(), lambda x: x.clone().requires_grad_(True))
+    bufs = O.camera_buffers(2, w, h, H.PX * h, H.PX * w, H.PX * h)
+    q0 = torch.nn.functional.normalize(torch.tensor([[0.98, 0.05, -0.12, 0.03], [0.95, -0.2, 0.1, 0.0]]), dim=-1)
+    t0 = torch.tensor([[0.15, -0.1, -1.2], [-0.3, 0.2, -0.9]])
+    gen = torch.Generator().manual_seed(21 + mode)
+    wimg = torch.rand(2, h, w, 3, generator=gen)
+    cmap = torch.from_numpy(H.gold("cmap.npz")["cyclic_cmap"]).float()
+    qc, tc = q0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    (O.render(spec, bufs, qc, tc, mode, 2, steps, H.EPS, cmap=cmap) * wimg).mean().backward()
+    named = O.spec_parameters(spec)
+    for cap in (None, 0):
+        if cap is not None:
+            monkeypatch.setattr(ops, "bwd_hard_capacity", cap)
+        module = H.spec_to_module(O.scene_test1_closed())
+        loop = H.make_loop(module, h, w, n=2)
+        loop.shader.cyclic_cmap = cmap.to(DEV)
+        qg, tg = q0.to(DEV).requires_grad_(True), t0.to(DEV).requires_grad_(True)
+        img = loop(qg, tg, mode, 2, steps)
+        assert img.shape == (2, h, w, 3)
+        (img * wimg.to(DEV)).mean().backward()
+        for name, got, want in (("orientation", qg.grad, qc.grad), ("translation", tg.grad, tc.grad)):
+            assert got.shape == want.shape
+            scale = max(1e-3, want.abs().max().item())
+            err = (got.cpu() - want).abs().max().item()
+            assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, (cap, name, err, scale)
+        for (pname, want), (_, got) in zip(named, module.named_parameters()):
+            assert (got.grad.cpu() - want.grad).abs().max().item() <= 1e-4, (cap, pname)
