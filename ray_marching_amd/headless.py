@@ -68,11 +68,15 @@ def to_rgba(images: torch.Tensor) -> torch.Tensor:
 
 
 class FrameSink:
-    """Headless Window: ``draw([H,W,4] fp32 device tensor)`` -> pinned host ring buffer (+ PPM files)."""
+    """Headless Window: ``draw([H,W,4] fp32 device tensor)`` -> pinned host ring buffer (+ one PPM / PNG / raw float32
+    file per frame when ``out_dir`` is given)."""
 
-    def __init__(self, width: int, height: int, name: str = "Window", out_dir: Optional[str] = None, ring: int = 2):
+    def __init__(self, width: int, height: int, name: str = "Window", out_dir: Optional[str] = None, ring: int = 2,
+                 file_format: str = "ppm"):
+        if file_format not in ("ppm", "png", "raw"):
+            raise ValueError("file_format must be 'ppm', 'png' or 'raw' (the [H,W,4] float32 frame as is)")
         self.width, self.height, self.name = width, height, name
-        self.out_dir = out_dir
+        self.out_dir, self.file_format = out_dir, file_format
         if out_dir:
             os.makedirs(out_dir, exist_ok=True)
         self._host = [torch.empty((height, width, 4), dtype=torch.float32).pin_memory() if torch.cuda.is_available()
@@ -103,7 +107,8 @@ class FrameSink:
         else:
             self._host[slot].copy_(tensor)
         if self.out_dir:
-            self.save_ppm(os.path.join(self.out_dir, f"frame_{self.frames:05d}.ppm"), slot)
+            path = os.path.join(self.out_dir, f"frame_{self.frames:05d}.{self.file_format}")
+            {"ppm": self.save_ppm, "png": self.save_png, "raw": self.save_raw}[self.file_format](path, slot)
         self.frames += 1
 
     def latest(self) -> torch.Tensor:
@@ -113,14 +118,42 @@ class FrameSink:
             self._events[slot].synchronize()
         return self._host[slot]
 
-    def save_ppm(self, path: str, slot: Optional[int] = None):
-        img = self.latest() if slot is None else self._host[slot]
-        if slot is not None and self._events[slot] is not None:
+    def _host_frame(self, slot: Optional[int]) -> torch.Tensor:
+        if slot is None:
+            return self.latest()
+        if self._events[slot] is not None:
             self._events[slot].synchronize()
-        rgb = (torch.nan_to_num(img[..., :3]).clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).contiguous()
+        return self._host[slot]
+
+    def _rgb8(self, slot: Optional[int]) -> torch.Tensor:
+        return (torch.nan_to_num(self._host_frame(slot)[..., :3]).clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).contiguous()
+
+    def save_ppm(self, path: str, slot: Optional[int] = None):
+        rgb = self._rgb8(slot)
         with open(path, "wb") as f:
             f.write(f"P6 {self.width} {self.height} 255\n".encode())
             f.write(rgb.numpy().tobytes())
+
+    def save_png(self, path: str, slot: Optional[int] = None):
+        """8-bit RGB PNG (zlib from the standard library: one IHDR, one IDAT, filter type 0 on every row)."""
+        import struct
+        import zlib
+        rows = self._rgb8(slot).numpy()
+        raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(self.height))
+
+        def chunk(tag: bytes, data: bytes) -> bytes:
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+        with open(path, "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n")
+            f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", self.width, self.height, 8, 2, 0, 0, 0)))
+            f.write(chunk(b"IDAT", zlib.compress(raw, 6)))
+            f.write(chunk(b"IEND", b""))
+
+    def save_raw(self, path: str, slot: Optional[int] = None):
+        """The frame exactly as Window.draw received it: H*W*4 little-endian float32 (NaNs and all)."""
+        with open(path, "wb") as f:
+            f.write(self._host_frame(slot).numpy().tobytes())
 
     def close(self):
         for ev in self._events:

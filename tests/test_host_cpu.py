@@ -358,6 +358,30 @@ def test_headless_stand_ins_follow_the_reference_contracts(tmp_path):
         sink.draw(rgba[:, :, :3])
     with pytest.raises(ValueError):
         sink.draw(rgba.double())
+    # PNG (decoded again with zlib: signature, IHDR, one IDAT of filter-0 rows) and the raw float32 frame
+    import struct
+    import zlib
+    png_sink = FrameSink(8, 6, out_dir=str(tmp_path / "png"), file_format="png")
+    png_sink.draw(rgba)
+    data = open(tmp_path / "png" / "frame_00000.png", "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    chunks, at = [], 8
+    while at < len(data):
+        n, tag = struct.unpack(">I", data[at:at + 4])[0], data[at + 4:at + 8]
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+        chunks.append((tag, body)); at += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (8, 6, 8, 2, 0, 0, 0)
+    rows = zlib.decompress(chunks[1][1])
+    want = (rgba[..., :3].clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
+    for y in range(6):
+        assert rows[y * 25] == 0 and rows[y * 25 + 1:(y + 1) * 25] == want[y].numpy().tobytes()
+    raw_sink = FrameSink(8, 6, out_dir=str(tmp_path / "raw"), file_format="raw")
+    raw_sink.draw(rgba)
+    assert open(tmp_path / "raw" / "frame_00000.raw", "rb").read() == rgba.numpy().tobytes()
+    with pytest.raises(ValueError):
+        FrameSink(8, 6, file_format="jpeg")
 
 
 def test_background_specialisation_policy(monkeypatch, tmp_path):
