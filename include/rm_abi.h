@@ -359,7 +359,7 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
  * minimum / maximum.  raw: the un-normalised values rm_render_forward left in `first_pass` ([n,3], channel 0 is read);
  * lohi: device {min, max} (rm_minmax_decode); grad_image: dL/d(image) [n,3]; grad_raw [n,3] out: channel 0 =
  * dL/d(un-normalised value), channels 1, 2 = 0 -- the `grad_image` rm_render_backward expects for these modes.
- * partials: RM_NORM_BWD_BLOCKS * 4 floats.  Two launches (block sums, then the elementwise combination); deterministic. */
+ * partials: RM_NORM_BWD_BLOCKS * 4 floats, 16-byte aligned.  Two launches (block sums, then the elementwise combination); deterministic. */
 #define RM_NORM_BWD_BLOCKS 1024
 int rm_shade_norm_backward(const float* raw, const float* grad_image, const float* lohi /*device [2]*/, int32_t mode,
                            float* grad_raw, float* partials, int64_t n_pixels, void* stream);

@@ -514,6 +514,7 @@ int rm_shade_norm_backward(const float* raw, const float* grad_image, const floa
   if (n_pixels < 0 || (n_pixels > 0 && (!raw || !grad_image || !lohi || !grad_raw || !partials)))
     return fail(RM_E_BADARG, "rm_shade_norm_backward: null buffer");
   if (n_pixels == 0) return RM_OK;
+  if (reinterpret_cast<uintptr_t>(partials) & 15) return fail(RM_E_BADARG, "rm_shade_norm_backward: partials must be 16-byte aligned");
   const int blocks = grid_for((n_pixels + 255) / 256, RM_NORM_BWD_BLOCKS);
   rm::k_shade_norm_bwd_a<<<blocks, 256, 0, (hipStream_t)stream>>>(raw, grad_image, lohi, mode, grad_raw, partials, n_pixels);
   if (int e = launched("k_shade_norm_bwd_a")) return e;
