@@ -535,7 +535,7 @@ int rm_camera_backward(const RmCamera* cam, const float* orientation, const floa
   rm::k_camera_bwd<<<cam->num_cameras * bpc, 256, 0, (hipStream_t)stream>>>(*cam, orientation, grad_pos, grad_dirs, partials,
                                                                             row_begin, row_end, bpc);
   if (int e = launched("k_camera_bwd")) return e;
-  rm::k_camera_bwd_finish<<<cam->num_cameras, 64, 0, (hipStream_t)stream>>>(partials, bpc, cam->num_cameras,
+  rm::k_camera_bwd_finish<<<cam->num_cameras, 256, 0, (hipStream_t)stream>>>(partials, bpc, cam->num_cameras,
                                                                             grad_orientation, grad_translation);
   return launched("k_camera_bwd_finish");
 }

@@ -1822,14 +1822,28 @@ __global__ void k_camera_bwd(RmCamera cam, const float* __restrict__ orientation
   if (threadIdx.x < 7) partials[((int64_t)c * blocks_per_cam + b) * 7 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ void k_camera_bwd_finish(const float* __restrict__ partials, int blocks_per_cam, int num_cameras,
+__global__ void __launch_bounds__(256) k_camera_bwd_finish(const float* __restrict__ partials, int blocks_per_cam, int num_cameras,
                                     float* __restrict__ gq, float* __restrict__ gt) {
-  int c = blockIdx.x, k = threadIdx.x;
-  if (c >= num_cameras || k >= 7) return;
-  float s = 0.0f;
-  for (int b = 0; b < blocks_per_cam; ++b) s += partials[((int64_t)c * blocks_per_cam + b) * 7 + k];
-  if (k < 4) { if (gq) gq[4 * c + k] = s; }
-  else if (gt) gt[3 * c + (k - 4)] = s;
+  // one block of 256 threads per camera: thread t takes the rows t, t + 256, ... of that camera's block sums, then a
+  // fixed tree (seven threads walking the rows one after the other were a chain of dependent loads)
+  __shared__ float red[7][256];
+  const int c = blockIdx.x;
+  if (c >= num_cameras) return;
+  float acc[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int b = threadIdx.x; b < blocks_per_cam; b += 256) {
+    const float* row = partials + ((int64_t)c * blocks_per_cam + b) * 7;
+    for (int k = 0; k < 7; ++k) acc[k] += row[k];
+  }
+  for (int k = 0; k < 7; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2)
+      for (int k = 0; k < 7; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s2];
+    __syncthreads();
+  }
+  const int k = threadIdx.x;
+  if (k < 4) { if (gq) gq[4 * c + k] = red[k][0]; }
+  else if (k < 7 && gt) gt[3 * c + (k - 4)] = red[k][0];
 }
 
 // appends the active lanes of a wave to the deferred-ray list (one returning atomic per wave)
