@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 11
+#define RM_ABI_VERSION 12
 
 enum {
   RM_DTYPE_F32 = 0,
@@ -116,6 +116,13 @@ typedef struct RmScene {
   int32_t n_grad_derived;  /* leading floats of the derived block that carry gradients (capsule constants); the rest
                               (cull bounds, bound tables) has none, so the backward kernels keep
                               n_params + n_grad_derived accumulators per ray */
+  const float* block;      /* device, n_params + n_derived fp32, or NULL: the FINISHED scene block (raw parameters, then the
+                              derived constants) as a previous launch left it in `block_out`.  Every block of a launch gathers
+                              the parameters and derives the constants (capsule axes, bounding spheres of the cull tests, bound
+                              tables) in its prologue -- 9-20 us for the closed 6-primitive scene, 120 us for the 32-primitive
+                              one, one thread walking the program -- unless it is handed the result here.  The kernels of a
+                              backward pass take the block of their forward pass (same parameters by construction: autograd) */
+  float* block_out;        /* device, n_params + n_derived fp32, or NULL: block 0 of the launch writes its staged block here */
 } RmScene;
 
 /* PinholeCamera buffers (rendering/ray_marching.py:26-50). */

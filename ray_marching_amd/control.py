@@ -59,8 +59,8 @@ class CapturedFrame:
             def __getattr__(self, name):
                 return getattr(cs, name)
 
-            def scene_struct(self, prm, device, table_=None):
-                return cs.scene_struct(params, device, table)
+            def scene_struct(self, prm, device, table_=None, **block):
+                return cs.scene_struct(params, device, table, **block)
 
         static = _Static()
 

@@ -39,7 +39,7 @@ constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU
 int check_static(const RmScene* sc);
 
 int check_scene(const RmScene* sc) {
-  if (!sc || !sc->program || (!sc->params && !sc->param_refs && sc->n_params > 0))
+  if (!sc || !sc->program || (!sc->params && !sc->param_refs && !sc->block && sc->n_params > 0))
     return fail(RM_E_BADARG, "scene: null program/params");
   if (sc->n_instr <= 0 || sc->n_instr > 4096 || sc->n_params < 0 || sc->n_derived < 0 ||
       sc->stack_floats < 0 || sc->n_slots < 0 || sc->n_grad_derived < 0 || sc->n_grad_derived > sc->n_derived)
@@ -379,7 +379,10 @@ int rm_render_forward(const RmScene* scene, const RmCamera* cam, const RmTetra* 
     rm::k_march_regen<G><<<gm, LM.block, LM.lds, (hipStream_t)stream>>>(a);
     if (int e = launched("k_march_regen")) return e;
     int gf = grid_for((wave_tiles + (LF.block >> 6) - 1) / (LF.block >> 6), tune_max_blocks() > 0 ? tune_max_blocks() : kMaxBlocks);
-    rm::k_render_finish<G><<<gf, LF.block, LF.lds, (hipStream_t)stream>>>(a);
+    // the second kernel takes the finished scene block the first one left (RmScene::block_out), when the caller gave room for it
+    rm::RenderArgs af = a;
+    if (a.scene.block_out && !a.scene.block) { af.scene.block = a.scene.block_out; af.scene.block_out = nullptr; }
+    rm::k_render_finish<G><<<gf, LF.block, LF.lds, (hipStream_t)stream>>>(af);
     return launched("k_render_finish");
   }
   // two instantiations: the plain inference frame, and the one that also records (trajectory / p_final / nexec / normal_u)

@@ -1224,13 +1224,29 @@ RM_DEV void stage_params(const RmScene& sc, float* s_params, int n_params) {
   }
 }
 
+// RmScene::block: the finished block of an earlier launch instead of gather + derive_constants (rm_abi.h)
+RM_DEV void load_scene_block(const RmScene& sc, float* s_params) {
+  for (int i = threadIdx.x; i < sc.n_params + sc.n_derived; i += blockDim.x) s_params[i] = sc.block[i];
+}
+// RmScene::block_out: block 0 leaves its staged block for later launches (call behind derive_constants' last barrier)
+RM_DEV void store_scene_block(const RmScene& sc, const float* s_params) {
+  if (sc.block_out && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < sc.n_params + sc.n_derived; i += blockDim.x) sc.block_out[i] = s_params[i];
+}
+
 RM_DEV void stage_scene(const RmScene& sc, float* s_params, int4* s_prog) {
-  stage_params(sc, s_params, sc.n_params);
   const int4* gprog = reinterpret_cast<const int4*>(sc.program);
   for (int i = threadIdx.x; i < sc.n_instr; i += blockDim.x) s_prog[i] = gprog[i];
-  __syncthreads();
-  auto ins = [s_prog](int pc) { return s_prog[pc]; };
-  derive_constants(ins, sc.n_instr, s_params);
+  if (sc.block) {
+    load_scene_block(sc, s_params);
+    __syncthreads();
+  } else {
+    stage_params(sc, s_params, sc.n_params);
+    __syncthreads();
+    auto ins = [s_prog](int pc) { return s_prog[pc]; };
+    derive_constants(ins, sc.n_instr, s_params);
+  }
+  store_scene_block(sc, s_params);
 }
 
 // --------------------------------------------------------------------------

@@ -108,10 +108,16 @@ struct StaticCfg {
       store.acc0 = Code::stack_floats + Code::n_slots;
       store.acc_row = backward ? smem + pb + (int)(threadIdx.x >> 6) * kAcc : nullptr;
     }
-    stage_params(sc, s_params, Code::n_params);
-    __syncthreads();
-    auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
-    derive_constants(ins, Code::n, s_params);
+    if (sc.block) {
+      load_scene_block(sc, s_params);
+      __syncthreads();
+    } else {
+      stage_params(sc, s_params, Code::n_params);
+      __syncthreads();
+      auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
+      derive_constants(ins, Code::n, s_params);
+    }
+    store_scene_block(sc, s_params);
     SceneT s;
     if constexpr (kRegParams) s.P.load(s_params); else s.P.p = s_params;
     s.lds = s_params;
@@ -421,12 +427,27 @@ struct NoDefer {
 #define RM_BWD_INLINE_STEPS 3     // moving steps a wave still walks itself before handing its active rays over
 #endif
 
+// Phase clocks of k_render_bwd (-DRM_BWD_STAMPS, profiles/bwd_phases.py): s_memtime at phase boundaries, per wave, summed
+// into workspace words 8..15 at the end of the kernel.  Compiled out otherwise.
+#ifdef RM_BWD_STAMPS
+struct Stamps {
+  unsigned long long t;
+  unsigned acc[8];
+  RM_DEV void start() { t = __builtin_readcyclecounter(); for (int k = 0; k < 8; ++k) acc[k] = 0; }
+  RM_DEV void mark(int k) { const unsigned long long now = __builtin_readcyclecounter(); acc[k] += (unsigned)((now - t) >> 4); t = now; }
+};
+#define RM_STAMP(st, k) do { if (st) (st)->mark(k); } while (0)
+#else
+struct Stamps {};
+#define RM_STAMP(st, k) do { } while (0)
+#endif
+
 // `defer(i, lambda, gv, active)`: called once, wave-wide, when more than RM_BWD_INLINE_STEPS non-converged steps
 // remain; returns (per lane) whether the ray was handed to the deferred-ray kernels, which then own its outputs.
 template <class SceneT, class DeferF = NoDefer, bool kSoa = false>
 RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const float* traj, int64_t traj_stride,
                         int64_t ray, int nexec, int steps, bool want_gv, V3& gv, bool early, int* walked = nullptr,
-                        DeferF defer = DeferF(), bool* deferred_out = nullptr) {
+                        DeferF defer = DeferF(), bool* deferred_out = nullptr, [[maybe_unused]] Stamps* stamps = nullptr) {
   if (deferred_out) *deferred_out = false;
   // `gv` by reference and a flag, not an optional pointer: a pointer that may be null pins the vector in
   // scratch memory (a load + store + vmcnt(0) per step).  The iterate of the NEXT step is fetched before
@@ -474,8 +495,10 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
     // how many of the next steps down stay at the anchor (for every ray of the wave)?  at least two, or the
     // plain per-step VJP below is cheaper
     if (i < 1 || !__all(near_anchor(win[0]))) break;
+    RM_STAMP(stamps, 2);
     float f0;
     const V3 n = scene.vjp_point(anchor, 1.0f, &f0);
+    RM_STAMP(stamps, 3);
     float G = 0.0f;
     bool done = false, more = true;
     V3 p_i = anchor;
@@ -494,9 +517,11 @@ RM_DEV V3 march_reverse(const SceneT& scene, V3 lam, V3 v, V3 p_final, const flo
       if (more) fill(i - 1);                                    // p_i = win[7] is step i; the window moves on
     }
     cur = p_i;
+    RM_STAMP(stamps, 4);
     // parameter gradients of the whole run at once: the reverse pass alone, on the tape the point-gradient pass left
     // (no scene evaluation since: the loop above only loaded iterates)
     if (__any(G != 0.0f)) scene.vjp_replay(anchor, G);
+    RM_STAMP(stamps, 5);
     if (walked) *walked += 2;
     if (done) { finish_frozen(i); return lam; }
   }
@@ -1888,7 +1913,14 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
   Tetra T = load_tetra(a.tetra);
   const int W = a.cam.width, H = a.cam.height, rows = a.row_end - a.row_begin;
   const int64_t ntiles = wave_tiles(a);
+  Stamps* stamps = nullptr;
+#ifdef RM_BWD_STAMPS
+  Stamps stamps_;
+  stamps_.start();
+  stamps = &stamps_;
+#endif
   for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
+    RM_STAMP(stamps, 7);            // (epilogue of the previous tile + the grab of this one; kernel set-up for the first)
     int cam, row, col;
     bool live = ray_of_lane(a, tc.tile, cam, row, col);
     if (!live) { cam = 0; row = 0; col = 0; }
@@ -2003,6 +2035,7 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
     V3 lam = mk3(0.0f, 0.0f, 0.0f);
     int walked = 0;
     bool deferred = false;
+    RM_STAMP(stamps, 0);
     if (a.mode != RM_MODE_VIGNETTE) {            // the vignette does not depend on the surface at all
       if constexpr (kKind == 2) {                // proximity: scene(p).clamp(1e-2, inf).log()
         const float dist = scene.eval(p);
@@ -2012,11 +2045,13 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
       } else {
         lam = normals_backward(scene, T, p, u, gn, kKind == 1 ? gi3.x : 0.0f, kKind == 1);
       }
+      RM_STAMP(stamps, 1);
       int ne = a.nexec ? a.nexec[li] : a.steps;
       const int64_t tslot = tc.tile * 64 + (threadIdx.x & 63);
       lam = march_reverse<decltype(scene), DeferToList, true>(scene, lam, v, p, a.traj, a.steps, tslot, ne, a.steps,
                                                               a.grad_dirs != nullptr, gv, a.flags & RM_FLAG_EARLY_OUT, &walked,
-                                                              DeferToList{a, li, tslot}, &deferred);
+                                                              DeferToList{a, li, tslot}, &deferred, stamps);
+      RM_STAMP(stamps, 6);
     }
     if (a.tile_cost && (threadIdx.x & 63) == 0) a.tile_cost[tc.tile] = walked;
     if constexpr (kKind == 3) {
@@ -2026,6 +2061,11 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
     }
     if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);
   }
+#ifdef RM_BWD_STAMPS
+  stamps_.mark(7);
+  if ((threadIdx.x & 63) == 0 && a.minmax)
+    for (int k = 0; k < 8; ++k) atomicAdd(&a.minmax[8 + k], stamps_.acc[k]);
+#endif
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }
 
@@ -2244,7 +2284,8 @@ __global__ void k_finish_grads(RmScene sc, const float* __restrict__ sums, float
       if (w.x != RM_OP_LINE) continue;
       float a[6];
       for (int k = 0; k < 6; ++k) {
-        if (sc.param_refs) { const RmParamRef r = sc.param_refs[w.y + k]; a[k] = ld_t(r.base, r.elem, r.dtype); }
+        if (sc.block) a[k] = sc.block[w.y + k];
+        else if (sc.param_refs) { const RmParamRef r = sc.param_refs[w.y + k]; a[k] = ld_t(r.base, r.elem, r.dtype); }
         else a[k] = sc.params[w.y + k];
       }
       float ab[3] = {a[3] - a[0], a[4] - a[1], a[5] - a[2]};

@@ -33,6 +33,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 _warned_f64: list = []
+use_forward_block = os.environ.get("RM_FORWARD_BLOCK", "1") != "0"      # A/B knob: backward kernels take the forward's scene block
 
 
 def _io(t: torch.Tensor):
@@ -476,7 +477,12 @@ class Render(torch.autograd.Function):
         park = torch.empty(int(_lib.rm_park_floats(park_cap)), dtype=torch.float32, device=dev) if park_cap else None
         with torch.cuda.device(dev):
             stream = _abi.current_stream(dev)
-            s, keep = cs.scene_struct(prm, dev)
+            # a training frame leaves its finished scene block (parameters + derived constants) for its backward
+            # kernels, which then skip the gather + derive_constants prologue (RmScene.block, include/rm_abi.h)
+            # (the ray pools' second kernel takes the block of their first one the same way)
+            block_out = torch.empty(max(cs.n_params + cs.n_derived, 1), dtype=torch.float32, device=dev) \
+                if (record or regen) and use_forward_block else None
+            s, keep = cs.scene_struct(prm, dev, block_out=block_out)
             cam = camera_struct(rp, rd)
             minmax = workspaces.take(dev, stream)      # global min/max words + tile-queue counters
             sink = event_sink if event_sink is not None else kernel_event_sink
@@ -548,7 +554,8 @@ class Render(torch.autograd.Function):
         lib = cs.lib(True, ctx.precision)
         with torch.cuda.device(dev):
             # the forward's own view of the parameters (its packed copy or pointer table): no second look at 40 storages
-            s, keep = cs.scene_struct(prm if prm is not None else ctx.scene_keep[1], dev, table=ctx.scene_keep[2])
+            s, keep = cs.scene_struct(prm if prm is not None else ctx.scene_keep[1], dev, table=ctx.scene_keep[2],
+                                      block=ctx.scene_keep[4] if use_forward_block else None)
             cam = camera_struct(rp, rd)
             part = _partials(cs, s, dev)
             stream = _abi.current_stream(dev)

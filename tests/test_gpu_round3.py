@@ -452,3 +452,40 @@ def test_two_camera_batch_trains(mode, monkeypatch):
             assert err <= 1e-4 * max(1.0, scale) and err <= 2e-3 * scale, (cap, name, err, scale)
         for (pname, want), (_, got) in zip(named, module.named_parameters()):
             assert (got.grad.cpu() - want.grad).abs().max().item() <= 1e-4, (cap, pname)
+
+
+def test_backward_kernels_take_the_forward_scene_block(monkeypatch):
+    """RmScene.block / block_out (ABI v12): block 0 of the recording forward leaves its finished scene block (parameters +
+    derived constants), and k_render_bwd / k_bwd_hard_n / k_bwd_hard_b read it instead of gathering the parameters and
+    deriving the constants again in every block (9-20 us per block for closed scene 1: the step 0.372 -> 0.340 ms at
+    512^2).  Same gradients bit for bit as with the prologue run in every kernel; and the backward differentiates the
+    frame that WAS rendered: parameters overwritten between forward and backward do not leak into it."""
+    from ray_marching_amd import ops
+    monkeypatch.setattr(ops, "bwd_hard_capacity", 0)          # in-place walk: bitwise reproducible parameter gradients
+    h, w, steps = 96, 128, 64
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -1.0]], device=DEV)
+    target = torch.rand(1, h, w, 1, generator=torch.Generator().manual_seed(5)).to(DEV)
+    grads = {}
+    for use in (False, True, "overwritten"):
+        monkeypatch.setattr(ops, "use_forward_block", bool(use))
+        module = H.spec_to_module(O.scene_test1_closed())
+        loop = H.make_loop(module, h, w)
+        loss = (loop(q, t, 0, 1, steps)[..., :1] - target).pow(2).mean()
+        if use == "overwritten":
+            saved = [p.detach().clone() for p in module.parameters()]
+            with torch.no_grad():
+                for p in module.parameters():
+                    p.data.mul_(1.5)                           # (.data: no version bump, autograd cannot notice)
+        loss.backward()
+        grads[use] = torch.cat([p.grad.flatten() for p in module.parameters()])
+    assert torch.equal(grads[False], grads[True])
+    assert torch.equal(grads["overwritten"], grads[True])
+    # ... and the pools' second kernel renders the same frame from the first one's block
+    with torch.no_grad():
+        frames = {}
+        for use in (False, True):
+            monkeypatch.setattr(ops, "use_forward_block", use)
+            loop = H.make_loop(H.spec_to_module(O.scene_test2()), 90, 160, regen=True)
+            frames[use] = [loop(q, torch.tensor([[0.0, 0.0, 1.0]], device=DEV), m, 1, 32) for m in (4, 0, 1)]
+        for a, b in zip(frames[False], frames[True]):
+            assert torch.equal(a, b)
