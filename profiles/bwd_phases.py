@@ -19,12 +19,13 @@ target = torch.rand(1, size, size, 1, device=dev)
 ops.bwd_tile_cost_sink = torch.zeros(int(ops._lib.rm_wave_tiles(1, size, size, 2)), dtype=torch.int32, device=dev)
 names = ["prologue: loads + shader VJP", "normals VJP (4-5 scene VJPs with parameters)", "reverse march: first iterates + vote",
          "  anchor point gradient (vjp_point)", "  converged-tail loop (iterate windows, votes, flops)", "  parameter replay (vjp_replay)",
-         "  deferral / in-place walk / frozen rest", "epilogue stores + next tile (atomic) + set-up"]
+         "  deferral / in-place walk / frozen rest", "between set-up and the first tile", "the next tile: returning atomic on the tile queues (steals, last look)",
+         "the tile's stores"]
 for it in range(3):
     for p in scene.parameters(): p.grad = None
     (loop(q, t, mode, 1, 64)[..., :1] - target).pow(2).mean().backward()
     torch.cuda.synchronize()
-    w = ops.bwd_last_work.cpu().tolist()[8:16]
+    w = ops.bwd_last_work.cpu().tolist()[8:18]
 tot = sum(w)
 print(f"k_render_bwd phases at {size}x{size}, mode {mode} (share of summed wave time; last of 3 steps)")
 for n, x in zip(names, w):

@@ -583,6 +583,10 @@ int rm_render_backward(const RmScene* scene, const RmCamera* cam, const RmTetra*
                                            : ((int64_t)cam->num_cameras * rows * W + 63) / 64;
   }
   int grid = grid_for((wave_tiles + (L.block >> 6) - 1) / (L.block >> 6), tune_bwd_blocks());
+  // Two tiles per wave or fewer (config 4 at 512^2: 4096 tiles, 2048 waves): the tile queues have nothing to balance, and
+  // every wave would end on a look at all of them -- static stride instead (same-box: 0.340 -> 0.329 ms per step at 512^2;
+  // at 1024^2, 8 tiles per wave, the queues win by 2 %: profiles/r03_train_ab.txt)
+  if (wave_tiles <= 2 * (int64_t)grid * (L.block >> 6) && !env_set("RM_BWD_DYNAMIC_TILES")) a.flags &= ~RM_FLAG_DYNAMIC_TILES;
   // deferred rays: only with the reverse early exit, a workspace for the list and its counter
   const bool defer = hard_ws && hard_capacity > 0 && work && (flags & RM_FLAG_EARLY_OUT) && steps > 0;
   if (defer) {

@@ -1160,9 +1160,18 @@ RM_DEV void derive_line_constants(GetIns ins, int pc, float* s_params) {
 // all derived constants of a program; call with every thread of the block (contains barriers)
 template <class GetIns>
 RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
-  __shared__ BoundFrame s_bound_stack[kBoundDepth];
+  // Bounding spheres: a walk over the subtree per cull site, a chain of dependent LDS reads and scalar-like flops on one
+  // lane (~1 us per instruction visited: 9 us for closed scene 1, 120 us for the 32-primitive scene with its bound
+  // table).  The sites are dealt round robin to the first lanes of the block's waves, each with its own stack.
+  constexpr int kWalkers = 4;
+  __shared__ BoundFrame s_bound_stacks[kWalkers][kBoundDepth];
   for (int i = threadIdx.x; i < n_instr; i += blockDim.x) derive_line_constants(ins, i, s_params);
-  if (threadIdx.x == 0) {     // bounding spheres: few, tiny, one after the other on one thread
+  const int walker = threadIdx.x >> 6;
+  const int n_walkers = ((int)(blockDim.x >> 6) < kWalkers) ? (int)(blockDim.x >> 6) : kWalkers;
+  if ((threadIdx.x & 63) == 0 && walker < n_walkers) {
+    BoundFrame* s_bound_stack = s_bound_stacks[walker];
+    int site = 0;
+    auto mine = [&]() { return (site++ % n_walkers) == walker; };
     for (int pc = 0; pc < n_instr; ++pc) {
       const int4 w = ins(pc);
       if (w.x == RM_OP_SMOOTH_BEGIN && w.z > 0) {
@@ -1179,6 +1188,7 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
             else if (op == RM_OP_UNION_END || op == RM_OP_SMOOTH_END) --depth;
             else if (op == RM_OP_FOLD_LSE && depth == 0) break;
           }
+          if (!mine()) { q = end + 1; continue; }
           float b[7];
           subtree_bound(ins, s_params, q, end, b, s_bound_stack);
           float* out = s_params + w.z + 8 * j;
@@ -1194,7 +1204,7 @@ RM_DEV void derive_constants(GetIns ins, int n_instr, float* s_params) {
           q = end + 1;
         }
       }
-      if (w.x == RM_OP_CULL_MIN) {
+      if (w.x == RM_OP_CULL_MIN && mine()) {
         float b7[7];
         float* out = s_params + w.z;
         subtree_bound(ins, s_params, pc + 1, pc + (w.w >> 8), b7, s_bound_stack);  // child without its FOLD

@@ -428,12 +428,12 @@ struct NoDefer {
 #endif
 
 // Phase clocks of k_render_bwd (-DRM_BWD_STAMPS, profiles/bwd_phases.py): s_memtime at phase boundaries, per wave, summed
-// into workspace words 8..15 at the end of the kernel.  Compiled out otherwise.
+// into workspace words 8..17 at the end of the kernel.  Compiled out otherwise.
 #ifdef RM_BWD_STAMPS
 struct Stamps {
   unsigned long long t;
-  unsigned acc[8];
-  RM_DEV void start() { t = __builtin_readcyclecounter(); for (int k = 0; k < 8; ++k) acc[k] = 0; }
+  unsigned acc[10];
+  RM_DEV void start() { t = __builtin_readcyclecounter(); for (int k = 0; k < 10; ++k) acc[k] = 0; }
   RM_DEV void mark(int k) { const unsigned long long now = __builtin_readcyclecounter(); acc[k] += (unsigned)((now - t) >> 4); t = now; }
 };
 #define RM_STAMP(st, k) do { if (st) (st)->mark(k); } while (0)
@@ -1919,8 +1919,9 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
   stamps_.start();
   stamps = &stamps_;
 #endif
-  for (TileCursor tc = first_wave_tile(a, ntiles); tc.tile < ntiles; next_wave_tile(a, ntiles, tc)) {
-    RM_STAMP(stamps, 7);            // (epilogue of the previous tile + the grab of this one; kernel set-up for the first)
+  TileCursor tc = first_wave_tile(a, ntiles);
+  RM_STAMP(stamps, 7);              // (what lies between the kernel's set-up and its first tile)
+  for (; tc.tile < ntiles; ) {
     int cam, row, col;
     bool live = ray_of_lane(a, tc.tile, cam, row, col);
     if (!live) { cam = 0; row = 0; col = 0; }
@@ -2060,11 +2061,13 @@ __global__ void __launch_bounds__(256) RM_BWD_OCC k_render_bwd(RenderArgs a) {
       if (live && !deferred && a.grad_pos) store3(a.grad_pos, li, lam);
     }
     if (live && !deferred && a.grad_dirs) store3(a.grad_dirs, li, gv);
+    RM_STAMP(stamps, 9);            // the tile's stores
+    next_wave_tile(a, ntiles, tc);
+    RM_STAMP(stamps, 8);            // the next tile (a returning atomic; at the end, the look at all the queues)
   }
 #ifdef RM_BWD_STAMPS
-  stamps_.mark(7);
   if ((threadIdx.x & 63) == 0 && a.minmax)
-    for (int k = 0; k < 8; ++k) atomicAdd(&a.minmax[8 + k], stamps_.acc[k]);
+    for (int k = 0; k < 10; ++k) atomicAdd(&a.minmax[8 + k], stamps_.acc[k]);
 #endif
   flush_accumulators<Cfg>(scene, n_acc, a.partials, rm_smem + ((a.scene.n_params + a.scene.n_derived + 3) & ~3));
 }

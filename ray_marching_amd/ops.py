@@ -33,6 +33,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 _warned_f64: list = []
+bwd_clear_flags = _abi.FLAG_DYNAMIC_TILES if os.environ.get("RM_BWD_STATIC_TILES", "0") == "1" else 0      # A/B knob
 use_forward_block = os.environ.get("RM_FORWARD_BLOCK", "1") != "0"      # A/B knob: backward kernels take the forward's scene block
 
 
@@ -579,7 +580,8 @@ class Render(torch.autograd.Function):
                                                _abi.ptr(part), _abi.ptr(work), _abi.ptr(gpos), _abi.ptr(gdirs),
                                                _abi.ptr(gqdir), _abi.ptr(cmap), 0 if cmap is None else cmap.shape[0],
                                                0 if cmap is None else _abi.dtype_code(cmap.dtype),
-                                               ctx.mode, ctx.degree, ctx.steps, ctx.rows[0], ctx.rows[1], ctx.flags,
+                                               ctx.mode, ctx.degree, ctx.steps, ctx.rows[0], ctx.rows[1],
+                                               ctx.flags & ~bwd_clear_flags,
                                                _abi.ptr(bwd_tile_cost_sink), _abi.ptr(hard), hard_cap, stream),
                        "rm_render_backward", lib)
         gq = gt = None
