@@ -18,7 +18,7 @@ out = {}
 q = torch.tensor([[1.0,0,0,0]], device=dev); t = torch.tensor([[0.0,0.0,-1.0]], device=dev)
 for size in (512, 1024):
     scene = make_closed_test_scene()
-    loop = RenderLoop(scene, num_cameras=1, px_width=size, px_height=size, focal_length=bench.PX*size, sensor_width=bench.PX*size, sensor_height=bench.PX*size, normals_eps=bench.EPS).to(dev)
+    loop = RenderLoop(scene, num_cameras=1, px_width=size, px_height=size, focal_length=bench.PX*size, sensor_width=bench.PX*size, sensor_height=bench.PX*size, normals_eps=bench.EPS, dynamic_tiles=os.environ.get('RM_AB_DYNAMIC', '1') == '1').to(dev)
     target = torch.rand(1, size, size, 1, device=dev)
     def step():
         (loop(q, t, 0, 1, 64)[..., :1] - target).pow(2).mean().backward()
