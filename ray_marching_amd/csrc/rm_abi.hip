@@ -145,7 +145,9 @@ int tune_block() { static int v = env_int("RM_BLOCK", 256); return v; }
 int tune_max_blocks() { static int v = env_int("RM_MAX_BLOCKS", 1280); return v; }
 // backward kernels: blocks of 128 threads; 1024 = 2 waves per SIMD (what 250-VGPR kernels can hold)
 int tune_bwd_blocks() { static int v = env_int("RM_BWD_BLOCKS", 1024); return v < 1 ? 1 : (v > kMaxBlocksBwd ? kMaxBlocksBwd : v); }
-int tune_hardb_blocks() { static int v = env_int("RM_HARDB_BLOCKS", 1024); return v < 1 ? 1 : (v > kHardBlocksB ? kHardBlocksB : v); }
+// k_bwd_hard_b holds 3 waves per SIMD (155 VGPRs): 1536 blocks of 2 waves fill them (1024 left a slot idle: 0.767 -> 0.755 ms per
+// config-4 step at 1024^2, 0.328 -> 0.326 at 512^2, once the scene block made blocks cheap; profiles/r03_train_ab.txt)
+int tune_hardb_blocks() { static int v = env_int("RM_HARDB_BLOCKS", 1536); return v < 1 ? 1 : (v > kHardBlocksB ? kHardBlocksB : v); }
 int tune_hardn_blocks() { static int v = env_int("RM_HARDN_BLOCKS", 2048); return v < 1 ? 1 : v; }
 
 int launched(const char* what) {
