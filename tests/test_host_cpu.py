@@ -636,3 +636,37 @@ def test_abi_header_is_plain_c():
         r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", src, "-o", os.path.join(tmp, "use.o")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_structs_have_the_layout_of_the_header():
+    """The ctypes mirrors in _abi.py (what every launch passes by pointer) against the C compiler's own layout of
+    include/rm_abi.h: size and every field offset of RmScene, RmCamera, RmTetra and RmParamRef (ABI v12 added
+    RmScene.block / block_out at the end)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from ray_marching_amd import _abi
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    structs = {"RmScene": _abi.RmScene, "RmCamera": _abi.RmCamera, "RmTetra": _abi.RmTetra}
+    lines = []
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({name}, {field}));')
+        lines.append('  printf("\\n");')
+    lines.append('  printf("RmParamRef %zu %zu %zu %zu\\n", sizeof(RmParamRef), offsetof(RmParamRef, base), offsetof(RmParamRef, elem), offsetof(RmParamRef, dtype));')
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, "layout.c"), os.path.join(tmp, "layout")
+        with open(src, "w") as f:
+            f.write('#include <stddef.h>\n#include <stdio.h>\n#include "rm_abi.h"\nint main(void) {\n' + "\n".join(lines) + "\n  return 0;\n}\n")
+        r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = subprocess.run([exe], capture_output=True, text=True).stdout.splitlines()
+    got = {line.split()[0]: [int(x) for x in line.split()[1:]] for line in out}
+    for name, cls in structs.items():
+        want = [C.sizeof(cls)] + [getattr(cls, field).offset for field, _ in cls._fields_]
+        assert got[name] == want, (name, got[name], want)
+    assert _abi.RmScene._fields_[-2][0] == "block" and _abi.RmScene._fields_[-1][0] == "block_out"
+    # the pointer table rows compiler.py writes: {int64 pointer, int64 elem | dtype << 32} = RmParamRef on a little-endian host
+    assert got["RmParamRef"] == [16, 0, 8, 12]
