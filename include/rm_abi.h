@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 12
+#define RM_ABI_VERSION 13
 
 enum {
   RM_DTYPE_F32 = 0,
@@ -123,6 +123,15 @@ typedef struct RmScene {
                               one, one thread walking the program -- unless it is handed the result here.  The kernels of a
                               backward pass take the block of their forward pass (same parameters by construction: autograd) */
   float* block_out;        /* device, n_params + n_derived fp32, or NULL: block 0 of the launch writes its staged block here */
+  float* block_cache;      /* device, n_params + n_derived fp32, or NULL: a finished block the launch may REUSE AFTER CHECKING IT.
+                              Every block gathers the live parameters as always and compares them, bit for bit, with the
+                              parameters the cache was derived from; equal: it takes the cached derived constants (the walk over
+                              the program is skipped: 2-5 us per block of the reference's scenes); different, or a cache the caller
+                              filled with 0xFFFFFFFF words: it derives them, and block 0 rewrites the cache (derived constants
+                              first, then -- behind a device-scope fence -- the parameters they belong to; readers load with
+                              device scope).  In-place edits, optimiser steps and .data writes are therefore seen by the very next
+                              launch, as without it.  One cache per stream: launches that may run concurrently must not share
+                              one.  Ignored when `block` is given or n_params == 0 */
 } RmScene;
 
 /* PinholeCamera buffers (rendering/ray_marching.py:26-50). */

@@ -14,7 +14,7 @@ import os
 # ROCm-capable device is detected" (seen on the GPU box with build() followed by smoke() in one process).
 import torch  # noqa: F401,E402
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _HERE = os.path.dirname(os.path.abspath(__file__))
 from ._build import LIB_PATH  # noqa: E402  (ray_marching_amd/lib/librm_hip.so, or under RM_LIB_DIR)
 
@@ -45,7 +45,8 @@ MODES = ("lambertian", "distance", "proximity", "vignette", "normal", "laplacian
 class RmScene(C.Structure):
     _fields_ = [("program", C.c_void_p), ("params", C.c_void_p), ("param_refs", C.c_void_p), ("n_instr", C.c_int32),
                 ("n_params", C.c_int32), ("n_derived", C.c_int32), ("stack_floats", C.c_int32),
-                ("n_slots", C.c_int32), ("n_grad_derived", C.c_int32), ("block", C.c_void_p), ("block_out", C.c_void_p)]
+                ("n_slots", C.c_int32), ("n_grad_derived", C.c_int32), ("block", C.c_void_p), ("block_out", C.c_void_p),
+                ("block_cache", C.c_void_p)]
 
 
 class RmCamera(C.Structure):

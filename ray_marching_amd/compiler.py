@@ -170,11 +170,12 @@ class CompiledScene:
         self._table = {"key": key, "value": table}
         return table
 
-    def scene_struct(self, params, device, table=None, block=None, block_out=None):
+    def scene_struct(self, params, device, table=None, block=None, block_out=None, block_cache=None):
         """RmScene for a launch; keeps the referenced tensors alive via the return tuple.  ``params``: the packed
         fp32 block, or None to gather from ``table`` (default: param_table(device)); packs when neither works.
         ``block``: the finished scene block (n_params + n_derived floats) a previous launch left in its ``block_out``:
-        the kernels then skip gathering the parameters and deriving the constants."""
+        the kernels then skip gathering the parameters and deriving the constants.  ``block_cache``: a block the kernels
+        reuse after comparing the parameters it was derived from with the live ones (ops.scene_caches)."""
         prog = self.device_program(device)
         if params is None and table is None:
             table = self.param_table(device)
@@ -186,8 +187,9 @@ class CompiledScene:
                          n_instr=self.n_instr, n_params=self.n_params, n_derived=self.n_derived,
                          stack_floats=self.stack_floats, n_slots=self.n_slots, n_grad_derived=self.n_grad_derived,
                          block=None if block is None else block.data_ptr(),
-                         block_out=None if block_out is None else block_out.data_ptr())
-        return s, (prog, params, table, block, block_out)
+                         block_out=None if block_out is None else block_out.data_ptr(),
+                         block_cache=None if block_cache is None else block_cache.data_ptr())
+        return s, (prog, params, table, block, block_out, block_cache)
 
 
 class _Emitter:

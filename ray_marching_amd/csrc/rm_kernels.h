@@ -113,9 +113,12 @@ struct StaticCfg {
       __syncthreads();
     } else {
       stage_params(sc, s_params, Code::n_params);
-      __syncthreads();
-      auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
-      derive_constants(ins, Code::n, s_params);
+      if (!try_scene_cache(sc, s_params)) {
+        __syncthreads();
+        auto ins = [](int pc) { const Ins& i = Code::code[pc]; return make_int4(i.op, i.off, i.a0, i.a1); };
+        derive_constants(ins, Code::n, s_params);
+        fill_scene_cache(sc, s_params);
+      }
     }
     store_scene_block(sc, s_params);
     SceneT s;

@@ -33,6 +33,24 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 _warned_f64: list = []
+use_scene_cache = os.environ.get("RM_SCENE_CACHE", "1") != "0"      # A/B knob
+
+
+def scene_cache(cs: CompiledScene, dev, stream):
+    """The validated scene-block cache of (scene, device, stream) -- launches on one stream are ordered, so they may share
+    one; created filled with 0xFFFFFFFF words (no parameter block compares equal to that).  None under graph capture
+    when none exists yet (its initialisation would be replayed with the graph), and for parameter-free scenes."""
+    if not use_scene_cache or cs.n_params <= 0:
+        return None
+    caches = cs.__dict__.setdefault("_block_caches", {})
+    key = (dev.index, int(getattr(stream, "value", stream) or 0))
+    buf = caches.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.full((cs.n_params + cs.n_derived,), -1, dtype=torch.int32, device=dev).view(torch.float32)
+        caches[key] = buf
+    return buf
 bwd_clear_flags = _abi.FLAG_DYNAMIC_TILES if os.environ.get("RM_BWD_STATIC_TILES", "0") == "1" else 0      # A/B knob
 use_forward_block = os.environ.get("RM_FORWARD_BLOCK", "1") != "0"      # A/B knob: backward kernels take the forward's scene block
 
@@ -483,7 +501,10 @@ class Render(torch.autograd.Function):
             # (the ray pools' second kernel takes the block of their first one the same way)
             block_out = torch.empty(max(cs.n_params + cs.n_derived, 1), dtype=torch.float32, device=dev) \
                 if (record or regen) and use_forward_block else None
-            s, keep = cs.scene_struct(prm, dev, block_out=block_out)
+            # inference frames: the derived constants of the previous launch on this stream, reused by the kernels when the
+            # parameters they gather are bit for bit the ones the cache was derived from (RmScene.block_cache)
+            cache = None if record else scene_cache(cs, dev, stream)
+            s, keep = cs.scene_struct(prm, dev, block_out=block_out, block_cache=cache)
             cam = camera_struct(rp, rd)
             minmax = workspaces.take(dev, stream)      # global min/max words + tile-queue counters
             sink = event_sink if event_sink is not None else kernel_event_sink

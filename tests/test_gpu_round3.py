@@ -489,3 +489,71 @@ def test_backward_kernels_take_the_forward_scene_block(monkeypatch):
             frames[use] = [loop(q, torch.tensor([[0.0, 0.0, 1.0]], device=DEV), m, 1, 32) for m in (4, 0, 1)]
         for a, b in zip(frames[False], frames[True]):
             assert torch.equal(a, b)
+
+
+def test_scene_cache_is_checked_against_the_live_parameters(monkeypatch):
+    """RmScene.block_cache (ABI v13): inference launches reuse the derived constants of the previous launch on their
+    stream ONLY when the parameters they gather are bit for bit the ones the cache belongs to.  Frames with the cache and
+    without are identical; an in-place edit, a `.data` write, an optimiser-style update and a value that moves a cull
+    bound are all seen by the very next frame (both kernel paths, both frame kernels); NaN parameters never match a
+    stale cache by accident; two streams keep separate caches."""
+    from ray_marching_amd import ops
+    from ray_marching_amd.compiler import compiled_for
+    h, w, steps = 72, 96, 48
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=DEV); t = torch.tensor([[0.0, 0.0, -3.0]], device=DEV)
+
+    def edits(module):
+        prm = dict(module.named_parameters())
+        names = list(prm)
+        yield "unchanged", lambda: None
+        yield "in-place", lambda: prm[names[0]].data.mul_(1.25)
+        yield ".data assignment", lambda: setattr(prm[names[1]], "data", prm[names[1]].data + 0.125)
+        yield "unchanged again", lambda: None
+        yield "every parameter", lambda: [p.data.add_(0.01 * torch.randn_like(p)) for p in prm.values()]
+        yield "back to a value seen before (the cache holds the latest only)", lambda: prm[names[0]].data.div_(1.25)
+
+    for path in ("off", "auto"):
+        monkeypatch.setenv("RM_SPECIALIZE", path)
+        for regen in (False, True):
+            torch.manual_seed(3)
+            cached_mod, plain_mod = H.spec_to_module(O.scene_test2()), H.spec_to_module(O.scene_test2())
+            cached, plain = H.make_loop(cached_mod, h, w, regen=regen), H.make_loop(plain_mod, h, w, regen=regen)
+            for (what, edit_a), (_, edit_b) in zip(edits(cached_mod), edits(plain_mod)):
+                torch.manual_seed(11); edit_a()
+                torch.manual_seed(11); edit_b()
+                with torch.no_grad():
+                    monkeypatch.setattr(ops, "use_scene_cache", True)
+                    a = [cached(q, t, m, 1, steps) for m in (4, 0)] + [cached(q, t, 4, 1, steps)]       # second frame of a value: a hit
+                    monkeypatch.setattr(ops, "use_scene_cache", False)
+                    b = [plain(q, t, m, 1, steps) for m in (4, 0)] + [plain(q, t, 4, 1, steps)]
+                for x, y in zip(a, b):
+                    assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), (path, regen, what)
+            monkeypatch.setattr(ops, "use_scene_cache", True)
+            assert compiled_for(cached_mod).__dict__.get("_block_caches"), "the cache was never created"
+            assert not compiled_for(plain_mod).__dict__.get("_block_caches")
+    # a NaN parameter: frames equal the uncached ones (NaN != NaN never lets a stale cache through: the compare is on bits,
+    # and the bits changed)
+    monkeypatch.setenv("RM_SPECIALIZE", "off")
+    mod_a, mod_b = H.spec_to_module(O.scene_test2()), H.spec_to_module(O.scene_test2())
+    la, lb = H.make_loop(mod_a, h, w), H.make_loop(mod_b, h, w)
+    with torch.no_grad():
+        la(q, t, 4, 1, steps)
+        for m in (mod_a, mod_b):
+            next(iter(m.parameters())).data.fill_(float("nan"))
+        monkeypatch.setattr(ops, "use_scene_cache", True)
+        xa = la(q, t, 4, 1, steps)
+        monkeypatch.setattr(ops, "use_scene_cache", False)
+        xb = lb(q, t, 4, 1, steps)
+    assert torch.equal(xa.isnan(), xb.isnan()) and torch.equal(torch.nan_to_num(xa, nan=-7.0), torch.nan_to_num(xb, nan=-7.0))
+    # a second stream gets its own cache
+    monkeypatch.setattr(ops, "use_scene_cache", True)
+    mod = H.spec_to_module(O.scene_test2())
+    loop = H.make_loop(mod, h, w)
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        x0 = loop(q, t, 4, 1, steps)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            x1 = loop(q, t, 4, 1, steps)
+        torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(x0, x1) and len(compiled_for(mod).__dict__["_block_caches"]) == 2

@@ -640,8 +640,8 @@ def test_abi_header_is_plain_c():
 
 def test_ctypes_structs_have_the_layout_of_the_header():
     """The ctypes mirrors in _abi.py (what every launch passes by pointer) against the C compiler's own layout of
-    include/rm_abi.h: size and every field offset of RmScene, RmCamera, RmTetra and RmParamRef (ABI v12 added
-    RmScene.block / block_out at the end)."""
+    include/rm_abi.h: size and every field offset of RmScene, RmCamera, RmTetra and RmParamRef (ABI v12 / v13 added
+    RmScene.block / block_out / block_cache at the end)."""
     import shutil
     import subprocess
     import tempfile
@@ -667,6 +667,6 @@ def test_ctypes_structs_have_the_layout_of_the_header():
     for name, cls in structs.items():
         want = [C.sizeof(cls)] + [getattr(cls, field).offset for field, _ in cls._fields_]
         assert got[name] == want, (name, got[name], want)
-    assert _abi.RmScene._fields_[-2][0] == "block" and _abi.RmScene._fields_[-1][0] == "block_out"
+    assert [f for f, _ in _abi.RmScene._fields_[-3:]] == ["block", "block_out", "block_cache"]
     # the pointer table rows compiler.py writes: {int64 pointer, int64 elem | dtype << 32} = RmParamRef on a little-endian host
     assert got["RmParamRef"] == [16, 0, 8, 12]
