@@ -89,6 +89,7 @@ class CompiledScene:
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_device_programs"], state["_table"], state["_lib"] = {}, {}, None
+        state.pop("_block_caches", None)          # (ops.scene_cache: per-stream device buffers)
         return state
 
     def lib(self, backward: bool = False, precision: str = "exact"):
