@@ -12,7 +12,7 @@ q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev); t = torch.tensor([[0.0, 0.
 ref = None
 variants = (("tile kernel", dict(regen=False)), ("ray pools", dict(regen=True)), ("tile kernel again", dict(regen=False)))
 if len(sys.argv) > 1 and sys.argv[1] == "pools":      # A/B of pool-kernel builds: RM_HIPCC_EXTRA=-D... RM_LIB_DIR=... RM_SPECIALIZE=jit
-    variants = (("ray pools " + os.environ.get("RM_HIPCC_EXTRA", ""), dict(regen=True)),)
+    variants = (("ray pools " + os.environ.get("RM_LABEL", os.environ.get("RM_HIPCC_EXTRA", "")), dict(regen=True)),)
 for name, kw in variants:
     loop = RenderLoop(make_many_primitive_scene(32), num_cameras=1, px_width=W, px_height=H, focal_length=bench.PX * H,
                       sensor_width=bench.PX * W, sensor_height=bench.PX * H, normals_eps=bench.EPS, **kw).to(dev)
